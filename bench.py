@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: images/sec of one training step (forward + loss + backward + SGD/EMA step) of the
+YOLOv5-backbone segmentation model (BASELINE config 2: C3_DCN -> C3, 640x640, bs=16 per GPU, Dice loss, 12 classes)
+on synthetic data.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = whole-job images/sec with inputs resident in HBM.  `roofline` is the
+dominant kernel family measured with events on the launch stream in an instrumented pass after the timed region;
+`cpu_baseline` is the CPU oracle (oracle/ref_cpu.py, kind "port") timed on this host on a bounded sample."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_IMG = 129.3e9          # algorithmic FLOP / image, fwd+bwd, live graph, convs only
+PEAK_BF16 = 2500.0       # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32 = 157.3         # TFLOP/s f32 MFMA
+PEAK_HBM = 8000.0        # GB/s
+
+
+def load_cfg():
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "yolo_dual_amd", "cfg", "yolov5_seg.yaml")))
+    for sec in ("backbone", "head"):
+        for l in cfg[sec]:
+            if l[2] == "C3_DCN":
+                l[2] = "C3"
+    return cfg
+
+
+def cpu_baseline(bs: int, size: int, steps: int):
+    """the CPU oracle's training step (fwd + CE+0.5*Dice + bwd + SGD-nesterov) on all host cores"""
+    import torch
+    from oracle import ref_cpu as R
+    from oracle.fill import fill_state_dict
+    from tests.model_shapes import script_model_state_shapes
+    cfg = load_cfg()
+    shapes = script_model_state_shapes(cfg)
+    sd = {k: (torch.zeros(s) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64))
+          for k, s in shapes.items()}
+    fill_state_dict(sd, 1, bn_stats=False)
+    pnames = [k for k in sd if k.endswith(".weight") or k.endswith(".bias")]
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(bs, 3, size, size, generator=g)
+    t = torch.randint(0, 12, (bs, size, size), generator=g)
+    cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+    bufs = {}
+    times = []
+    for st in range(steps + 1):
+        t0 = time.perf_counter()
+        ps = {k: sd[k].detach().clone().requires_grad_(True) for k in pnames}
+        run = dict(sd)
+        run.update(ps)
+        out = R.script_model_forward(run, cfg, x, (size, size))
+        total, _, _ = R.seg_loss(out, t, cw, "dice")
+        total.backward()
+        for k in pnames:
+            if ps[k].grad is not None:
+                wd = 5e-4 if k.endswith("conv.weight") else 0.0
+                bufs[k] = R.sgd_nesterov_step(sd[k], ps[k].grad, bufs.get(k), 0.01, 0.937, wd)
+        for k in sd:
+            if k not in ps:
+                sd[k] = run[k]
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / max(len(times) - 1, 1)
+    return {"value": bs / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (1 warm-up) of the same model/loss/optimizer at bs={bs}, {size}x{size}, fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bs", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd.parallel import DataParallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ydl.set_compute_dtype(args.dtype)
+
+    torch.manual_seed(0)
+    model = ydl.YOLOv5Seg(load_cfg()).to(dev).train()
+    model.img_size = [args.size, args.size]
+    cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)   # weight.yaml:3-14
+    crit = ydl.SegmentationLoss(12, 0.0, cw, "dice", sync=False)
+    # reference hyper-parameters: lr0 0.01, momentum 0.937, weight_decay 5e-4 * bs*accumulate/64 with accumulate=1
+    opt = ydl.FlatSGDEMA(model, lr=0.01, momentum=0.937, weight_decay=5e-4 * args.bs * world / 64.0, ema=(rank == 0))
+    dp = DataParallel(model, opt) if world > 1 else None
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    imgs = torch.rand(args.bs, 3, args.size, args.size, device=dev, generator=g)
+    tgts = torch.randint(0, 12, (args.bs, args.size, args.size), device=dev, generator=g)
+
+    def step():
+        opt.zero_grad()
+        if dp:
+            dp.begin()
+        out = model(imgs)
+        loss, items = crit(out, tgts)
+        loss.backward()
+        scale = dp.finish() if dp else 1.0
+        opt.step(grad_scale=scale)
+        return items
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        items = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(items[0])
+    ips = args.bs * world * args.steps / dt
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        L.profile_begin()
+        for _ in range(3):
+            step()
+        rec = L.profile_end()
+        if args.profile_json:
+            with open(args.profile_json, "w") as fh:
+                json.dump(rec, fh)
+        fam = {}
+        for r in rec:
+            f = fam.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "n": 0})
+            f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["n"] += 1
+        tot_ms = sum(f["ms"] for f in fam.values())
+        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        name, f = dom
+        peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
+        if f["flops"] > 0:
+            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": ach / peak, "traffic": None, "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
+                    "share_of_gpu_time": f["ms"] / tot_ms}
+        else:
+            roof = {"bound": "hbm", "kernel": name, "achieved": None, "peak": PEAK_HBM, "unit": "GB/s", "frac": None,
+                    "traffic": None, "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
+                    "share_of_gpu_time": f["ms"] / tot_ms}
+        roof["by_kernel_ms_per_step"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        roof["end_to_end_mfma_frac"] = ips / world * F_IMG / 1e12 / peak
+
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(2, args.size, args.cpu_steps)
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec at 640x640 bs=16/GPU", "value": ips, "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic", "loss": loss_val,
+            "config": {"workload": "YOLOv5-backbone (C3+SPPF) + UNet-lite SegmentHead, fwd+bwd+SGD/EMA step, "
+                                   f"{args.size}x{args.size}, bs={args.bs}/GPU, CE+0.5*Dice, 12 classes (BASELINE configs[1])",
+                       "global_batch": args.bs * world, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": base}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/*
+ * ydl.h — C ABI of libydl_hip.so: the MI355X (gfx950) kernels behind the segmentation training hot path.
+ *
+ * Drop-in boundary.  The reference has no native ABI on its live path (it calls ATen through
+ * nn.Module.forward); the only native interface it ships is the orphan DCNv3 pybind pair
+ * (models/ops_dcnv3/src/cuda/dcnv3_cuda.h:15-31).  This header is what a reference-side binding (ctypes /
+ * pybind) would bind to replace, per op, the ATen calls made by:
+ *   Conv.forward            unet-lite/yolo5-seg/seg_diceloss_yolov5.py:403-409  (models/common.py:57-64)
+ *   C3/C2f/SPPF/Concat      seg_diceloss_yolov5.py:416-507, yolov8/seg_jaccardloss_yolov8.py:401-414
+ *   nn.Upsample / interpolate  seg_diceloss_yolov5.py:588-609, 655-657
+ *   SegmentHead             segment/train.py:159-210
+ *   SegmentationLoss        seg_diceloss_yolov5.py:712-750, yolov8/seg_jaccardloss_yolov8.py:774-815
+ *   smart_optimizer + ModelEMA.update   utils/torch_utils.py:318-346, 404-428
+ *   dcnv3_forward/backward  models/ops_dcnv3/src/cuda/dcnv3_cuda.h:15-31
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; all pointers are DEVICE pointers unless named h_*.
+ *  - The caller owns every buffer (outputs, workspaces); kernels never allocate or synchronise.
+ *  - Every entry point takes the HIP stream explicitly (void* = hipStream_t) and is re-entrant.
+ *  - Return value: 0 on success, non-zero on error; ydl_last_error() gives a thread-local message.
+ *  - Activations are NHWC: element (n,h,w,c) of a tensor with pixel stride `ld` lives at
+ *    base[((n*H + h)*W + w)*ld + c].  `ld >= C`, `ld*sizeof(elem)` and `base` must be 16-byte aligned.
+ *    A channel slice of a wider buffer (free concat) is just base+c0 with the wide ld.
+ *  - dtype: YDL_F32 (exact-parity mode, f32 MFMA) or YDL_BF16 (throughput mode, bf16 MFMA, f32 accumulate).
+ */
+#ifndef YDL_H_
+#define YDL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { YDL_F32 = 0, YDL_BF16 = 1 };
+enum { YDL_ACT_NONE = 0, YDL_ACT_SILU = 1, YDL_ACT_RELU = 2 };
+/* residual handling of the fused BN/activation kernels */
+enum { YDL_RES_NONE = 0, YDL_RES_AFTER_ACT = 1 /* C3/C2f: act(bn(y)) + r */, YDL_RES_BEFORE_ACT = 2 /* ResNet: act(bn(y) + r) */ };
+enum { YDL_LOSS_DICE = 0, YDL_LOSS_JACCARD = 1 };
+
+const char* ydl_last_error(void);
+int ydl_version(void);
+/* debug knobs for A/B tests: key 0 = wgrad transposed-LDS-read path on (1, default) / off (0) */
+void ydl_debug_set(int key, int val);
+
+/* ---- convolution as implicit GEMM on MFMA ------------------------------------------------------------
+ * Geometry of one conv layer (square kernel k, stride s, padding p, groups=1, no bias).
+ * Weights in compute layout: w  = [Cout][k*k][Cin_p]   (KRSC; Cin_p = Cin rounded up to 8)
+ *                            wt = [Cin][k*k][Cout_p]   (transposed, for dgrad; Cout_p = Cout rounded up to 8)
+ */
+typedef struct {
+    int N, Hi, Wi, Cin;       /* input  (Cin = logical channels; reads Cin_p = round_up(Cin, 8) <= ldx) */
+    int Ho, Wo, Cout;         /* output */
+    int k, s, p;
+    int ldx, ldy;             /* pixel strides of x and y (elements) */
+} ydl_conv_geom;
+
+/* BN-statistics workspace of the forward epilogue: [grid_m][2][round_up(Cout,8)] floats, where block b of
+ * the launch covered min(block_m, N*Ho*Wo - b*block_m) pixels.  The three queries are pure functions of g. */
+int64_t ydl_conv_fwd_stats_ws_bytes(const ydl_conv_geom* g, int dtype);
+int ydl_conv_fwd_grid_m(const ydl_conv_geom* g);
+int ydl_conv_fwd_block_m(const ydl_conv_geom* g);
+
+/* y = conv(x, w).  If stats_ws != NULL the epilogue also writes per-block (sum, M2) partials of y per output
+ * channel (from the f32 accumulators) for train-mode BN; finish them with ydl_bn_finalize. */
+int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
+                 float* stats_ws, void* stream);
+/* dx (+)= conv_transpose(dy, wt).  accumulate != 0 adds into dx (gradient fan-in). */
+int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
+                   int accumulate, void* stream);
+/* dw[Cout][k*k][Cin_p] (f32) += sum over pixels dy^T * im2col(x).  dw must be zeroed (or hold the running
+ * sum for gradient accumulation) before the call: split-K blocks add with f32 atomics. */
+int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream);
+
+/* master weights (f32, KRSC [Cout][k*k][Cin]) -> compute copies: w [Cout][kk][Cin_p] and wt [Cin][kk][Cout_p] */
+int ydl_weight_prep(int dtype, const float* master, void* w, void* wt, int Cout, int kk, int Cin, void* stream);
+/* dw [Cout][kk][Cin_p] f32 -> master-layout grad [Cout][kk][Cin] (only needed when Cin_p != Cin) */
+int ydl_wgrad_unpad(const float* dw, float* grad, int Cout, int kk, int Cin, int accumulate, void* stream);
+
+/* ---- train-mode BatchNorm + activation ------------------------------------------------------------- */
+/* Chan-merge the per-block partials; writes mean/invstd (saved for backward), scale=gamma*invstd,
+ * shift=beta-mean*scale; updates running_mean/var (momentum, unbiased var) and is a no-op on them if NULL. */
+int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, int64_t count, int C,
+                    const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval-mode: scale/shift from running statistics */
+int ydl_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* out = act(y*scale+shift) [+ res] ; res_mode per YDL_RES_*.  Cp = channels processed (multiple of 8). */
+int ydl_bn_act_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                   const void* res, int ldr, int res_mode, int act, void* out, int ldo,
+                   int64_t npix, int Cp, void* stream);
+int64_t ydl_bn_bwd_ws_bytes(int64_t npix, int Cp);
+/* Backward of out = act(bn(y)) [+res].  dout: grad wrt out.  out: saved output (needed only for RELU).
+ * Writes dy (grad wrt conv output), dgamma/dbeta (f32, accumulate flag), and for YDL_RES_BEFORE_ACT the
+ * masked gradient dres (may be NULL otherwise; for RES_AFTER_ACT the residual gradient is dout itself). */
+int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                   const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
+                   int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                   float* dgamma, float* dbeta, int accumulate_param_grads,
+                   float* ws, int64_t npix, int C, int Cp, void* stream);
+
+/* ---- spatial ops (NHWC, channel-vectorised) -------------------------------------------------------- */
+/* max pool (k,s,p), -inf padding; idx (uint8 window offset of the arg-max, first max in scan order) is
+ * written when non-NULL and consumed by the backward. */
+int ydl_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int ldy, uint8_t* idx,
+                    int N, int Hi, int Wi, int Ho, int Wo, int C, int k, int s, int p, void* stream);
+int ydl_maxpool_bwd(int dtype, const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, int accumulate,
+                    int N, int Hi, int Wi, int Ho, int Wo, int C, int k, int s, int p, void* stream);
+/* resize: mode 0 nearest (src=min(floor(dst*scale),in-1)), 1 bilinear align_corners=False, 2 bilinear
+ * align_corners=True.  scale_h/w <= 0 means "derive from sizes" (in/out, or (in-1)/(out-1)). */
+int ydl_resize_fwd(int dtype, int mode, const void* x, int ldx, void* y, int ldy,
+                   int N, int Hi, int Wi, int Ho, int Wo, int C, float scale_h, float scale_w, void* stream);
+int ydl_resize_bwd(int dtype, int mode, const void* dy, int lddy, void* dx, int lddx, int accumulate,
+                   int N, int Hi, int Wi, int Ho, int Wo, int C, float scale_h, float scale_w, void* stream);
+/* strided channel-slice copy / add:  dst[:, 0:C] (op)= src[:, 0:C] */
+int ydl_copy2d(int dtype, const void* src, int lds, void* dst, int ldd, int64_t npix, int C, int accumulate,
+               void* stream);
+/* layout/dtype conversion at the model edge: NCHW f32 <-> NHWC compute dtype (channels padded with zeros) */
+int ydl_nchw_to_nhwc(int dtype, const float* src, void* dst, int ldd, int N, int C, int H, int W, void* stream);
+int ydl_nhwc_to_nchw(int dtype, const void* src, int lds, float* dst, int N, int C, int H, int W, int accumulate,
+                     void* stream);
+/* generic elementwise on NHWC slices: out = a * b_bcast ... used by GAM (x * gate[n,c]) */
+int ydl_scale_channels(int dtype, const void* x, int ldx, const float* gate /*[N][C]*/, void* y, int ldy,
+                       int N, int64_t hw, int C, void* stream);
+
+/* ---- softmax over channels (the yaml models end in nn.Softmax(1)) ----------------------------------- */
+/* x: NHWC compute dtype (C<=32); p: f32 with element strides (sn, sc, sh, sw) — NCHW or NHWC. */
+int ydl_softmax_fwd(int dtype, const void* x, int ldx, float* p, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                    int N, int H, int W, int C, void* stream);
+/* dx = p * (dp - sum_c p*dp) */
+int ydl_softmax_bwd(int dtype, const float* p, const float* dp, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                    void* dx, int lddx, int N, int H, int W, int C, void* stream);
+
+/* ---- CE + 0.5*(Dice|Jaccard) loss ------------------------------------------------------------------ */
+/* ws layout (f32): see ydl_seg_loss_ws_floats.  losses[0..2] = total, ce, overlap-loss (device, no sync). */
+int64_t ydl_seg_loss_ws_floats(int N, int C);
+int ydl_seg_loss_fwd(const float* pred, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                     const int64_t* target, int Ht, int Wt, const float* class_weights /* NULL = ones */,
+                     int kind, float label_smoothing, float eps, int N, int C, int H, int W,
+                     float* ws, float* losses, void* stream);
+/* dpred = dloss * dL/dpred, using the sums left in ws by the forward */
+int ydl_seg_loss_bwd(const float* pred, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                     const int64_t* target, int Ht, int Wt, const float* class_weights,
+                     int kind, float label_smoothing, float eps, int N, int C, int H, int W,
+                     const float* ws, const float* dloss /* device scalar, NULL = 1 */, float* dpred, void* stream);
+
+/* ---- optimizer: SGD(nesterov) + EMA on flat arenas --------------------------------------------------- */
+/* params/grads/momentum are flat f32 arenas laid out [decay group | no-decay group]; ema spans
+ * n_params + n_buffers (BN running stats follow the params in both `params` and `ema`).
+ * first_step != 0: momentum buffer is initialised with the gradient (torch.optim.SGD semantics). */
+int ydl_sgd_ema_step(float* params, const float* grads, float* momentum, float* ema,
+                     int64_t n_decay, int64_t n_params, int64_t n_total,
+                     float lr_decay_group, float lr_nodecay_group, float mom, float weight_decay, float grad_scale,
+                     int first_step, float ema_decay /* <0: skip EMA */, void* stream);
+
+/* ---- evaluation: argmax + confusion matrix (val_diceloss.py:37-75) ---------------------------------- */
+int ydl_confusion_matrix(const float* pred, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                         const int64_t* target, int N, int C, int H, int W, int ignore_index,
+                         int64_t* matrix /* [C][C], accumulated */, void* stream);
+
+/* ---- DCNv3 (models/ops_dcnv3/src/cuda/dcnv3_cuda.h:15-31; argument order kept) ---------------------- */
+int ydl_dcnv3_fwd(int dtype, const void* input, const void* offset, const void* mask, void* output,
+                  int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                  int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
+                  int N, int H_in, int W_in, int H_out, int W_out, void* stream);
+/* grad_input must be zeroed by the caller (f32 atomics); grad_offset/grad_mask are fully written. */
+int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, const void* mask, const void* grad_output,
+                  float* grad_input, float* grad_offset, float* grad_mask,
+                  int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                  int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
+                  int N, int H_in, int W_in, int H_out, int W_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YDL_H_ */

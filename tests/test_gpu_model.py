@@ -1,0 +1,182 @@
+"""GPU parity of whole models against the reference's own 2-step training trajectories (tests/golden/model_*.npz),
+plus size-independent properties at the benchmark's full size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle.fill import fill_state_dict
+from tests.util import Golden, rel_err
+
+pytestmark = pytest.mark.gpu
+CW = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+CFG = os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg")
+
+
+def _cfg(name, swap):
+    cfg = yaml.safe_load(open(os.path.join(CFG, name)))
+    for sec in ("backbone", "head"):
+        for l in cfg[sec]:
+            l[2] = swap.get(l[2], l[2])
+    return cfg
+
+
+def _train_check(g, model, crit, mode, steps=2, lr=0.01):
+    import yolo_dual_amd as ydl
+    ydl.set_compute_dtype(mode)
+    # bf16 at this toy size (64x64, batch 2: the deepest BatchNorms see 8 values per channel) only checks the loss and
+    # the dead-parameter set; bf16 accuracy at a realistic size is test_bf16_tracks_f32 below
+    tol = dict(f32=dict(out=1e-4, loss=1e-4, gn=2e-3, fin=2e-3), bf16=dict(out=None, loss=5e-2, gn=None, fin=None))[mode]
+    sd = model.state_dict()
+    fill_state_dict(sd, 1234, bn_stats=False)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    # the reference run used torch.optim.SGD(model.parameters(), lr, momentum=0.937, nesterov=True): one group, no decay
+    opt = ydl.FlatSGDEMA(model, lr=lr, momentum=0.937, weight_decay=0.0, ema=False)
+    x, tgt = g.t("x").cuda(), g.t("target").cuda()
+    for st in range(steps):
+        opt.zero_grad()
+        out = model(x)
+        total, items = crit(out, tgt)
+        total.backward()
+        if st == 0:
+            assert list(out.shape) == [int(v) for v in g.flat["out_shape"]]
+            vals = out.detach().flatten()[g.t("out_idx").cuda()].cpu()
+            e = rel_err(vals, g.t("out_vals"))
+            assert tol["out"] is None or e < tol["out"], ("logits", e)
+            named = dict(model.named_parameters())
+            none = sorted(k for k, p in named.items() if not getattr(p, "_ydl_touched", False))
+            assert none == sorted(g.strs("grad_none")), "set of parameters without gradient differs (SURVEY T4)"
+            bad = []
+            for k, n in zip(g.strs("grad_names"), g.flat["grad_norms"]):
+                got = float(named[k].grad.double().norm())
+                if tol["gn"] is not None and abs(got - n) > tol["gn"] * max(n, 1e-7):
+                    bad.append((k, got, n))
+            assert not bad, bad[:5]
+        ref = g.flat[f"loss_items_{st}"]
+        for a, b in zip(items, ref):
+            assert abs(a - b) <= tol["loss"] * abs(b), (st, items, ref)
+        opt.step()
+    sd = model.state_dict()
+    bad = []
+    for k, s, a in zip(g.strs("final_keys"), g.flat["final_sums"], g.flat["final_abs"]):
+        got = float(sd[k].double().sum())
+        if tol["fin"] is not None and abs(got - s) > tol["fin"] * max(a, 1e-6):
+            bad.append((k, got, s, a))
+    assert not bad, bad[:5]
+    ydl.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_yolov5seg_trajectory(mode):
+    import yolo_dual_amd as ydl
+    g = Golden("model_yolov5seg_64")
+    m = ydl.YOLOv5Seg(_cfg("yolov5_seg.yaml", {"C3_DCN": "C3"}))
+    m.img_size = [64, 64]
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode)
+
+
+@pytest.mark.parametrize("mode", ["f32"])
+def test_yolov8seg_trajectory(mode):
+    import yolo_dual_amd as ydl
+    g = Golden("model_yolov8seg_64")
+    m = ydl.YOLOv8Seg(_cfg("yolov8_seg.yaml", {"C2f_DCN": "C2f"}))
+    m.img_size = [64, 64]
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "jaccard"), mode)
+
+
+@pytest.mark.parametrize("mode", ["f32"])
+def test_resnet18seg_trajectory(mode):
+    import yolo_dual_amd as ydl
+    g = Golden("model_resnet18seg_64")
+    m = ydl.ResNet18Seg({"nc": 12})
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, None, "dice"), mode)
+
+
+def test_bf16_tracks_f32():
+    """throughput mode vs parity mode of the same kernels at a realistic size (256x256, batch 4): probabilities and
+    loss of the bf16 path stay close to the f32 path (which is pinned to the reference at 1e-4)."""
+    import yolo_dual_amd as ydl
+    from tests.util import l2_err
+    res = {}
+    for mode in ("f32", "bf16"):
+        ydl.set_compute_dtype(mode)
+        m = ydl.YOLOv5Seg(_cfg("yolov5_seg.yaml", {"C3_DCN": "C3"}))
+        m.img_size = [256, 256]
+        sd = m.state_dict()
+        fill_state_dict(sd, 99, bn_stats=False)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        crit = ydl.SegmentationLoss(12, 0.0, CW, "dice")
+        gen = torch.Generator("cuda").manual_seed(5)
+        x = torch.rand(4, 3, 256, 256, device="cuda", generator=gen)
+        t = torch.randint(0, 12, (4, 256, 256), device="cuda", generator=gen)
+        out = m(x)
+        total, items = crit(out, t)
+        total.backward()
+        res[mode] = (out.detach().float().cpu(), items, m.backbone[0].conv.weight.grad.detach().float().cpu().clone())
+    ydl.set_compute_dtype("bf16")
+    assert l2_err(res["bf16"][0], res["f32"][0]) < 0.1
+    assert abs(res["bf16"][1][0] - res["f32"][1][0]) <= 1e-2 * abs(res["f32"][1][0])
+    assert l2_err(res["bf16"][2], res["f32"][2]) < 0.25        # stem weight gradient: the longest bf16 chain
+
+
+def test_wgrad_transposed_read_matches_scalar_read():
+    """A/B the ds_read_b64_tr_b16 operand path of the bf16 wgrad kernel against the scalar-LDS-read path."""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    ydl.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    res = []
+    for tr in (1, 0):
+        L.lib().ydl_debug_set(0, tr)
+        m = ydl.Conv(64, 96, 3, 1).cuda().train()
+        torch.manual_seed(1)
+        with torch.no_grad():
+            m.conv.weight.normal_(0, 0.05)
+        x = torch.randn(2, 64, 20, 24, device="cuda", generator=torch.Generator("cuda").manual_seed(2)).requires_grad_(True)
+        out = m(x)
+        out.square().sum().backward()
+        res.append(m.conv.weight.grad.detach().clone())
+    L.lib().ydl_debug_set(0, 1)
+    assert rel_err(res[0].cpu(), res[1].cpu()) < 1e-5       # same products, different atomic order only
+
+
+def test_full_size_properties():
+    """BASELINE config-2 size (bs=16 would need ~10 GB of activations; bs=4 keeps the test quick): size-independent
+    checks — probabilities sum to 1, finite loss, every live parameter gets a finite non-zero gradient, and the
+    dead-parameter set equals the one of the small golden run."""
+    import yolo_dual_amd as ydl
+    ydl.set_compute_dtype("bf16")
+    g = Golden("model_yolov5seg_64")
+    m = ydl.YOLOv5Seg(_cfg("yolov5_seg.yaml", {"C3_DCN": "C3"})).cuda().train()
+    opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.937, weight_decay=5e-4)
+    crit = ydl.SegmentationLoss(12, 0.0, CW, "dice")
+    gen = torch.Generator("cuda").manual_seed(0)
+    x = torch.rand(4, 3, 640, 640, device="cuda", generator=gen)
+    t = torch.randint(0, 12, (4, 640, 640), device="cuda", generator=gen)
+    opt.zero_grad()
+    out = m(x)
+    assert out.shape == (4, 12, 640, 640)
+    s = out.sum(1)
+    assert float((s - 1).abs().max()) < 1e-4
+    total, items = crit(out, t)
+    assert np.isfinite(items).all()
+    total.backward()
+    named = dict(m.named_parameters())
+    none = sorted(k for k, p in named.items() if not getattr(p, "_ydl_touched", False))
+    assert none == sorted(g.strs("grad_none"))
+    for k, p in named.items():
+        if getattr(p, "_ydl_touched", False):
+            gn = float(p.grad.float().norm())
+            assert np.isfinite(gn) and gn > 0, k
+    before = float(items[0])
+    opt.step()
+    for _ in range(3):
+        opt.zero_grad()
+        total, items = crit(m(x), t)
+        total.backward()
+        opt.step()
+    assert items[0] < before, "loss did not decrease on a fixed batch"

@@ -1,0 +1,137 @@
+"""ctypes binding of libydl_hip.so (include/ydl.h).  The product path has NO fallback: if the library is missing
+or a call fails, we raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libydl_hip.so")
+
+YDL_F32, YDL_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
+LOSS_DICE, LOSS_JACCARD = 0, 1
+RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BILINEAR_AC = 0, 1, 2
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("N", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Cin", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
+                ("k", C.c_int), ("s", C.c_int), ("p", C.c_int),
+                ("ldx", C.c_int), ("ldy", C.c_int)]
+
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+_G = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); mirrors include/ydl.h one to one
+SIGNATURES = {
+    "ydl_last_error": (C.c_char_p, []),
+    "ydl_version": (_i, []),
+    "ydl_debug_set": (None, [_i, _i]),
+    "ydl_conv_fwd_stats_ws_bytes": (_i64, [_G, _i]),
+    "ydl_conv_fwd_grid_m": (_i, [_G]),
+    "ydl_conv_fwd_block_m": (_i, [_G]),
+    "ydl_conv_fwd": (_i, [_G, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ydl_conv_dgrad": (_i, [_G, _i, _vp, _vp, _vp, _i, _vp]),
+    "ydl_conv_wgrad": (_i, [_G, _i, _vp, _vp, _vp, _vp]),
+    "ydl_weight_prep": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ydl_wgrad_unpad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ydl_bn_finalize": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ydl_bn_eval_coeffs": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "ydl_bn_act_fwd": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i64, _i, _vp]),
+    "ydl_bn_bwd_ws_bytes": (_i64, [_i64, _i]),
+    "ydl_bn_act_bwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i,
+                            _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
+    "ydl_maxpool_fwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ydl_maxpool_bwd": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ydl_resize_fwd": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "ydl_resize_bwd": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "ydl_copy2d": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
+    "ydl_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ydl_nhwc_to_nchw": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ydl_scale_channels": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i64, _i, _vp]),
+    "ydl_softmax_fwd": (_i, [_i, _vp, _i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
+    "ydl_softmax_bwd": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ydl_seg_loss_ws_floats": (_i64, [_i, _i]),
+    "ydl_seg_loss_fwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ydl_seg_loss_bwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ydl_sgd_ema_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "ydl_confusion_matrix": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ydl_dcnv3_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp]),
+    "ydl_dcnv3_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f,
+                           _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the CDLL; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m yolo_dual_amd.build` (hipcc, gfx950). "
+                "There is no CPU/PyTorch fallback for the kernels.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+class YdlError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ydl_last_error()
+        raise YdlError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+_PROFILE = None     # list of (name, start_event, end_event, geom-or-None) while profiling is on
+
+
+def profile_begin() -> None:
+    """Bracket every C-ABI launch with events on torch's current stream (the stream the kernels are launched on)."""
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """-> list of dicts {name, ms, flops} (flops only for the conv entry points: 2*M*K*Cout, logical channels)."""
+    global _PROFILE
+    import torch
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    out = []
+    for name, e0, e1, g in rec:
+        flops = 0.0
+        if g is not None:
+            flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.k * g.k * g.Cin
+        d = {"name": name, "ms": e0.elapsed_time(e1), "flops": flops}
+        if g is not None:
+            d["geom"] = [getattr(g, f) for f, _ in ConvGeom._fields_]
+        out.append(d)
+    return out
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise on error."""
+    if _PROFILE is None:
+        check(getattr(lib(), name)(*args), name)
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(getattr(lib(), name)(*args), name)
+    e1.record()
+    g = None
+    if name in ("ydl_conv_fwd", "ydl_conv_dgrad", "ydl_conv_wgrad"):
+        src = args[0]._obj
+        g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
+    _PROFILE.append((name, e0, e1, g))

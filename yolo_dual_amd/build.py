@@ -1,0 +1,54 @@
+"""Build libydl_hip.so (gfx950) in-tree with hipcc.  `python -m yolo_dual_amd.build` or __graft_entry__.build()."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libydl_hip.so")
+SOURCES = ["err.cpp", "igemm.hip", "bn.hip", "spatial.hip", "loss.hip", "optim.hip", "dcnv3.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "ydl.h")]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print("[build]", " ".join(cmd[-4:]), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

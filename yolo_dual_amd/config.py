@@ -1,0 +1,46 @@
+"""Process-wide settings of the HIP path."""
+from __future__ import annotations
+
+_STATE = {"dtype": "bf16", "weight_epoch": 0}
+
+
+def set_compute_dtype(name: str) -> None:
+    """'bf16' (throughput mode: bf16 storage + bf16 MFMA, f32 accumulate/statistics) or 'f32' (parity mode: f32
+    storage + exact f32 MFMA)."""
+    if name not in ("bf16", "f32"):
+        raise ValueError("compute dtype must be 'bf16' or 'f32'")
+    _STATE["dtype"] = name
+
+
+def compute_dtype() -> str:
+    return _STATE["dtype"]
+
+
+def weight_epoch() -> int:
+    return _STATE["weight_epoch"]
+
+
+def bump_weight_epoch() -> None:
+    """Called by optimizers that update parameter memory behind torch's version counters (the fused flat
+    SGD+EMA kernel) so that Conv modules refresh their compute-layout weight copies."""
+    _STATE["weight_epoch"] += 1
+
+
+_GRAD_HOOKS = []
+
+
+def add_grad_hook(fn) -> None:
+    """fn(param) is called right after the kernels that write ``param.grad`` have been enqueued (data-parallel
+    bucket triggering)."""
+    _GRAD_HOOKS.append(fn)
+
+
+def remove_grad_hook(fn) -> None:
+    if fn in _GRAD_HOOKS:
+        _GRAD_HOOKS.remove(fn)
+
+
+def mark_touched(p) -> None:
+    p._ydl_touched = True
+    for fn in _GRAD_HOOKS:
+        fn(p)

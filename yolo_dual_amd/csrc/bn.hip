@@ -1,0 +1,365 @@
+// Train-mode BatchNorm + activation (+ residual) for NHWC activations: statistics finalize, fused apply,
+// and the two-phase backward.  All kernels are HBM-bound streaming passes with 16-byte accesses.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// finalize: Chan-merge of the per-block (sum, M2) partials written by the conv epilogue.
+// partials: [nblocks][2][ldp]; block b covered n_b = min(block_m, count - b*block_m) pixels.
+// Two levels so that no thread walks a long dependent chain: level 1 (grid.y = chunks of MERGE_CHUNK blocks)
+// merges each chunk to one (sum, M2) partial; level 2 merges the chunk partials and writes the coefficients.
+// A CTA is 32 channels x 8 slices; merges are done in double.
+// ------------------------------------------------------------------------------------------------------
+#define MERGE_CHUNK 64
+
+// merges blocks [b0, b1) for channel c; every thread of the CTA must call it (uses LDS + barriers).
+// returns (sum, M2, n) on slice 0 threads.
+__device__ __forceinline__ void chan_merge(const float* __restrict__ part, int b0, int b1, int block_m, long long count,
+                                           int c, bool cvalid, int ldp, double& tot_o, double& m2_o, double& n_o) {
+    __shared__ double sh[8][33];
+    __shared__ double smean[32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double s = 0.0;
+    if (cvalid)
+        for (int b = b0 + sl; b < b1; b += 8) s += (double)part[(size_t)b * 2 * ldp + c];
+    sh[sl][cl] = s;
+    __syncthreads();
+    long long n_lo = (long long)b0 * block_m, n_hi = (long long)b1 * block_m;
+    if (n_hi > count) n_hi = count;
+    const double ntot = (double)(n_hi - n_lo);
+    if (sl == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 8; ++i) tot += sh[i][cl];
+        smean[cl] = tot / ntot;
+        tot_o = tot;
+    }
+    __syncthreads();
+    const double mu = smean[cl];
+    double m2 = 0.0;
+    if (cvalid)
+        for (int b = b0 + sl; b < b1; b += 8) {
+            long long nb = count - (long long)b * block_m;
+            if (nb > block_m) nb = block_m;
+            double sb = (double)part[(size_t)b * 2 * ldp + c];
+            double d = sb / (double)nb - mu;
+            m2 += (double)part[(size_t)b * 2 * ldp + ldp + c] + (double)nb * d * d;
+        }
+    __syncthreads();
+    sh[sl][cl] = m2;
+    __syncthreads();
+    if (sl == 0) {
+        double t2 = 0.0;
+        for (int i = 0; i < 8; ++i) t2 += sh[i][cl];
+        m2_o = t2;
+        n_o = ntot;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_merge_level1_kernel(const float* __restrict__ part, int nblocks, int block_m,
+                                                              long long count, int C, int ldp, float* __restrict__ part2) {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int b0 = blockIdx.y * MERGE_CHUNK;
+    const int b1 = min(nblocks, b0 + MERGE_CHUNK);
+    double tot = 0, m2 = 0, n = 0;
+    chan_merge(part, b0, b1, block_m, count, c, c < C, ldp, tot, m2, n);
+    if ((threadIdx.x >> 5) == 0 && c < C) {
+        part2[(size_t)blockIdx.y * 2 * ldp + c] = (float)tot;
+        part2[(size_t)blockIdx.y * 2 * ldp + ldp + c] = (float)m2;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int block_m,
+                                                          long long count, int C, int ldp,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* running_mean, float* running_var,
+                                                          float* mean_o, float* invstd_o, float* scale_o, float* shift_o) {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double tot = 0, m2 = 0, n = 0;
+    chan_merge(part, 0, nblocks, block_m, count, c, c < C, ldp, tot, m2, n);
+    if ((threadIdx.x >> 5) == 0 && c < C) {
+        double mu = tot / (double)count;
+        double var = m2 / (double)count;            // biased (normalisation)
+        float meanf = (float)mu;
+        float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        mean_o[c] = meanf;
+        invstd_o[c] = invstd;
+        float sc = g * invstd;
+        scale_o[c] = sc;
+        shift_o[c] = bt - meanf * sc;
+        if (running_mean) {
+            double unb = count > 1 ? m2 / (double)(count - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+extern "C" int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, int64_t count, int C,
+                               const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift, void* stream) {
+    YDL_CHECK(stats_ws && mean && invstd && scale && shift, "null pointer");
+    YDL_CHECK(nblocks > 0 && block_m > 0 && count > 0 && C > 0, "bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int ldp = round_up(C, 8);
+    const float* src = stats_ws;
+    if (nblocks > 2 * MERGE_CHUNK) {
+        // level 1 writes behind the level-0 partials (the workspace query reserves the room)
+        int nchunks = (nblocks + MERGE_CHUNK - 1) / MERGE_CHUNK;
+        float* part2 = const_cast<float*>(stats_ws) + (size_t)nblocks * 2 * ldp;
+        bn_merge_level1_kernel<<<dim3((C + 31) / 32, nchunks), 256, 0, st>>>(stats_ws, nblocks, block_m, (long long)count, C, ldp, part2);
+        src = part2;
+        nblocks = nchunks;
+        block_m *= MERGE_CHUNK;
+    }
+    bn_finalize_kernel<<<(C + 31) / 32, 256, 0, st>>>(src, nblocks, block_m, (long long)count, C, ldp, gamma, beta, eps,
+                                                      momentum, running_mean, running_var, mean, invstd, scale, shift);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float sc = gamma[c] / sqrtf(rv[c] + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+extern "C" int ydl_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    YDL_CHECK(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bad arguments");
+    bn_eval_coeffs_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, gamma, beta, running_mean, running_var, eps, scale, shift);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// apply: out = act(y*scale + shift) (+res).  One 16-byte chunk per thread iteration, grid-stride.
+// scale/shift arrays must be readable up to Cp (padded entries = 0 => padded channels stay 0 for SiLU/none).
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                                         int res_mode, int act, T* __restrict__ out, int ldo,
+                                                         long long npix, int Cp) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = npix * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pix = i / cpp;
+        int c = (int)(i - pix * cpp) * V;
+        float v[V], r[V];
+        unpack16<T>(*(const uint4*)(y + pix * ldy + c), v);
+        if (res_mode != YDL_RES_NONE) unpack16<T>(*(const uint4*)(res + pix * ldr + c), r);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float z = v[e] * scale[c + e] + shift[c + e];
+            if (res_mode == YDL_RES_BEFORE_ACT) z += r[e];
+            float o = act == YDL_ACT_SILU ? silu_f(z) : (act == YDL_ACT_RELU ? fmaxf(z, 0.f) : z);
+            if (res_mode == YDL_RES_AFTER_ACT) o += r[e];
+            v[e] = o;
+        }
+        *(uint4*)(out + pix * ldo + c) = pack16<T>(v);
+    }
+}
+
+static inline int stream_grid(long long total_items) {
+    long long b = (total_items + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int ydl_bn_act_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                              const void* res, int ldr, int res_mode, int act, void* out, int ldo,
+                              int64_t npix, int Cp, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    YDL_CHECK(y && out && scale && shift, "null pointer");
+    YDL_CHECK(Cp > 0 && Cp % V == 0 && ldy >= Cp && ldo >= Cp, "Cp must be a chunk multiple covered by the strides");
+    YDL_CHECK(res_mode == YDL_RES_NONE || (res != nullptr && ldr >= Cp), "residual requested but missing");
+    YDL_CHECK(aligned16(y) && aligned16(out) && (res == nullptr || aligned16(res)), "16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = stream_grid(npix * (Cp / V));
+    if (dtype == YDL_F32)
+        bn_act_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)y, ldy, scale, shift, (const float*)res, ldr, res_mode, act, (float*)out, ldo, npix, Cp);
+    else
+        bn_act_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)y, ldy, scale, shift, (const bf16_t*)res, ldr, res_mode, act, (bf16_t*)out, ldo, npix, Cp);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward.  dz = dout * act'(z);  dbeta = sum dz;  dgamma = sum dz*xhat;
+//            dy = gamma*invstd * (dz - dbeta/M - xhat*dgamma/M)
+// phase 1: per-block partial (dbeta, dgamma) ; phase 2: tiny merge ; phase 3: streaming apply.
+// ws layout (floats): [nblk][2][Cp] partials, then [2][Cp] merged sums.
+// ------------------------------------------------------------------------------------------------------
+#define BWD_MAX_PARTIALS 256      // the merge kernel walks nblk/8 partials per thread: keep the chain short
+#define BWD_MIN_PIX_PER_BLOCK 256
+
+static inline long long bwd_pix_per_block(long long npix) {
+    long long per = (npix + BWD_MAX_PARTIALS - 1) / BWD_MAX_PARTIALS;
+    if (per < BWD_MIN_PIX_PER_BLOCK) per = BWD_MIN_PIX_PER_BLOCK;
+    return per;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_dz(const T* y, const T* dout, const T* out, long long pix, int ldy, int lddo, int ldo,
+                                        int c, const float* scale, const float* shift, const float* mean,
+                                        const float* invstd, int act, float* dz, float* xh) {
+    constexpr int V = ET<T>::V;
+    float yv[V], dv[V], ov[V];
+    unpack16<T>(*(const uint4*)(y + pix * ldy + c), yv);
+    unpack16<T>(*(const uint4*)(dout + pix * lddo + c), dv);
+    if (act == YDL_ACT_RELU) unpack16<T>(*(const uint4*)(out + pix * ldo + c), ov);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        float z = yv[e] * scale[c + e] + shift[c + e];
+        float d = dv[e];
+        if (act == YDL_ACT_SILU) {
+            float sg = sigmoid_f(z);
+            d *= sg * (1.f + z * (1.f - sg));
+        } else if (act == YDL_ACT_RELU) {
+            d = ov[e] > 0.f ? d : 0.f;
+        }
+        dz[e] = d;
+        xh[e] = (yv[e] - mean[c + e]) * invstd[c + e];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int lddo,
+                                                            const T* __restrict__ out, int ldo,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int act, float* __restrict__ part, long long npix, int Cp,
+                                                            long long pix_per_block) {
+    constexpr int V = ET<T>::V;
+    const int cpp_all = Cp / V;                       // chunks per pixel
+    const int cgrp = min(cpp_all - blockIdx.y * 256, 256);   // chunks handled by this block column
+    const int cq = threadIdx.x % cgrp, pl = threadIdx.x / cgrp;
+    const int npl = 256 / cgrp;                       // pixel lanes
+    const int c = (blockIdx.y * 256 + cq) * V;
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    const long long p1 = min(npix, p0 + pix_per_block);
+    float sb[V], sg[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sb[e] = 0.f; sg[e] = 0.f; }
+    if (pl < npl)
+        for (long long pix = p0 + pl; pix < p1; pix += npl) {
+            float dz[V], xh[V];
+            load_dz<T>(y, dout, out, pix, ldy, lddo, ldo, c, scale, shift, mean, invstd, act, dz, xh);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
+        }
+    // reduce over pixel lanes through LDS
+    __shared__ float red[256 * 2 * 8];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        red[(threadIdx.x * 2 + 0) * V + e] = sb[e];
+        red[(threadIdx.x * 2 + 1) * V + e] = sg[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < cgrp) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float a = 0.f, b = 0.f;
+            for (int l = 0; l < npl; ++l) {
+                int tt = l * cgrp + threadIdx.x;
+                a += red[(tt * 2 + 0) * V + e];
+                b += red[(tt * 2 + 1) * V + e];
+            }
+            float* dst = part + (size_t)blockIdx.x * 2 * Cp;
+            dst[c + e] = a;
+            dst[Cp + c + e] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restrict__ part, int nblk, int Cp, int C,
+                                                           float* __restrict__ sums, float* dgamma, float* dbeta, int accumulate) {
+    __shared__ double sh[2][8][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < Cp)
+        for (int i = sl; i < nblk; i += 8) {
+            a += (double)part[(size_t)i * 2 * Cp + c];
+            b += (double)part[(size_t)i * 2 * Cp + Cp + c];
+        }
+    sh[0][sl][cl] = a;
+    sh[1][sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < Cp) {
+        double ta = 0.0, tb = 0.0;
+        for (int i = 0; i < 8; ++i) { ta += sh[0][i][cl]; tb += sh[1][i][cl]; }
+        sums[c] = (float)ta;          // dbeta
+        sums[Cp + c] = (float)tb;     // dgamma
+        if (c < C) {
+            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)ta : (float)ta;
+            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tb : (float)tb;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int lddo,
+                                                           const T* __restrict__ out, int ldo,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ sums, int act, T* __restrict__ dy, int lddy,
+                                                           T* __restrict__ dres, int lddr, long long npix, int Cp) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = npix * cpp;
+    const float invM = 1.0f / (float)npix;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pix = i / cpp;
+        int c = (int)(i - pix * cpp) * V;
+        float dz[V], xh[V], o[V];
+        load_dz<T>(y, dout, out, pix, ldy, lddo, ldo, c, scale, shift, mean, invstd, act, dz, xh);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = scale[c + e] * (dz[e] - (sums[c + e] + xh[e] * sums[Cp + c + e]) * invM);
+        *(uint4*)(dy + pix * lddy + c) = pack16<T>(o);
+        if (dres != nullptr) *(uint4*)(dres + pix * lddr + c) = pack16<T>(dz);
+    }
+}
+
+extern "C" int64_t ydl_bn_bwd_ws_bytes(int64_t npix, int Cp) {
+    int64_t nblk = cdiv64(npix, bwd_pix_per_block(npix));
+    return (nblk * 2 * Cp + 2 * Cp) * (int64_t)sizeof(float);
+}
+
+extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                              const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
+                              int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                              float* dgamma, float* dbeta, int accumulate_param_grads,
+                              float* ws, int64_t npix, int C, int Cp, void* stream) {
+    (void)gamma; (void)res_mode;
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    YDL_CHECK(y && dout && dy && mean && invstd && scale && shift && ws, "null pointer");
+    YDL_CHECK(act != YDL_ACT_RELU || out != nullptr, "RELU backward needs the saved output");
+    YDL_CHECK(Cp > 0 && Cp % V == 0 && C <= Cp && ldy >= Cp && lddo >= Cp && lddy >= Cp, "bad channel geometry");
+    YDL_CHECK(aligned16(y) && aligned16(dout) && aligned16(dy), "16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const long long ppb = bwd_pix_per_block(npix);
+    int nblk = (int)cdiv64(npix, ppb);
+    float* part = ws;
+    float* sums = ws + (size_t)nblk * 2 * Cp;
+    dim3 g1(nblk, (Cp / V + 255) / 256);
+    int g3 = stream_grid(npix * (Cp / V));
+    if (dtype == YDL_F32) {
+        bn_bwd_reduce_kernel<float><<<g1, 256, 0, st>>>((const float*)y, ldy, (const float*)dout, lddo, (const float*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp, ppb);
+        bn_bwd_merge_kernel<<<(Cp + 31) / 32, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
+        bn_bwd_apply_kernel<float><<<g3, 256, 0, st>>>((const float*)y, ldy, (const float*)dout, lddo, (const float*)out, ldo, scale, shift, mean, invstd, sums, act, (float*)dy, lddy, (float*)dres, lddr, npix, Cp);
+    } else {
+        bn_bwd_reduce_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, lddo, (const bf16_t*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp, ppb);
+        bn_bwd_merge_kernel<<<(Cp + 31) / 32, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
+        bn_bwd_apply_kernel<bf16_t><<<g3, 256, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, lddo, (const bf16_t*)out, ldo, scale, shift, mean, invstd, sums, act, (bf16_t*)dy, lddy, (bf16_t*)dres, lddr, npix, Cp);
+    }
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,172 @@
+// DCNv3 (grouped, mask-modulated deformable sampling, NHWC) forward / backward for gfx950.
+// Behaviour follows models/ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh:216-275 (forward) and :82-147 (gradients);
+// the decomposition is ours: a (pixel, group) item is owned by a power-of-two lane segment of one wavefront
+// (lanes = group channels, so every NHWC access is a contiguous run), and the grad_offset / grad_mask sums over the
+// channels are wavefront-shuffle butterflies instead of the reference's shared-memory trees.
+#include "common.h"
+
+struct DcnArgs {
+    const void* in; const void* off; const void* msk; void* out;        // fwd
+    const void* gout; float* gin; float* goff; float* gmsk;             // bwd
+    int kh, kw, sh, sw, ph, pw, dh, dw, G, Gc;
+    float scale;
+    int N, H, W, Ho, Wo;
+    int seg;          // lanes per item (power of two, <= 64)
+    long long items;  // N*Ho*Wo*G
+};
+
+__device__ __forceinline__ float seg_sum(float v, int seg) {
+    for (int o = seg >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void dcnv3_kernel(const DcnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int ipw = 64 / a.seg;                          // items per wave
+    const int sub = lane / a.seg, cl = lane % a.seg;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int P = a.kh * a.kw;
+    const int C = a.G * a.Gc;
+    const T* in = (const T*)a.in;
+    const T* off = (const T*)a.off;
+    const T* msk = (const T*)a.msk;
+    const long long rounds = (a.items + ipw - 1) / ipw;
+    for (long long rd = wave_id; rd < rounds; rd += nwaves) {
+        long long item = rd * ipw + sub;
+        bool live = item < a.items;
+        long long it = live ? item : 0;
+        int g = (int)(it % a.G);
+        long long pix = it / a.G;
+        int wo = (int)(pix % a.Wo);
+        long long t2 = pix / a.Wo;
+        int ho = (int)(t2 % a.Ho);
+        int n = (int)(t2 / a.Ho);
+        const int p0w = ((a.dw * (a.kw - 1)) >> 1) - a.pw + wo * a.sw;
+        const int p0h = ((a.dh * (a.kh - 1)) >> 1) - a.ph + ho * a.sh;
+        const float p0w_ = (float)p0w - (float)((a.dw * (a.kw - 1)) >> 1) * a.scale;
+        const float p0h_ = (float)p0h - (float)((a.dh * (a.kh - 1)) >> 1) * a.scale;
+        const T* offp = off + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2;
+        const T* mskp = msk + (size_t)pix * a.G * P + (size_t)g * P;
+        const T* imb = in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
+        for (int c0 = 0; c0 < a.Gc; c0 += a.seg) {
+            const int c = c0 + cl;
+            const bool act = live && c < a.Gc;
+            float col = 0.f;
+            float go = 0.f;
+            if (BWD && act) go = ET<T>::ld((const T*)a.gout + (size_t)pix * C + g * a.Gc + c);
+            int k = 0;
+            for (int i = 0; i < a.kw; ++i)
+                for (int j = 0; j < a.kh; ++j, ++k) {
+                    float ow = live ? ET<T>::ld(offp + 2 * k) : 0.f, oh = live ? ET<T>::ld(offp + 2 * k + 1) : 0.f;
+                    float mk = live ? ET<T>::ld(mskp + k) : 0.f;
+                    float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
+                    float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
+                    float gmask = 0.f, goffw = 0.f, goffh = 0.f;
+                    if (lh_ > -1.f && lw_ > -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
+                        int hl = (int)floorf(lh_), wl = (int)floorf(lw_);
+                        int hh_ = hl + 1, wh_ = wl + 1;
+                        float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
+                        float hh = 1.f - lh, hw = 1.f - lw;
+                        bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wh_ <= a.W - 1;
+                        bool b3 = hh_ <= a.H - 1 && wl >= 0, b4 = hh_ <= a.H - 1 && wh_ <= a.W - 1;
+                        size_t o1 = ((size_t)hl * a.W + wl) * C + c, o2 = ((size_t)hl * a.W + wh_) * C + c;
+                        size_t o3 = ((size_t)hh_ * a.W + wl) * C + c, o4 = ((size_t)hh_ * a.W + wh_) * C + c;
+                        float v1 = (act && b1) ? ET<T>::ld(imb + o1) : 0.f;
+                        float v2 = (act && b2) ? ET<T>::ld(imb + o2) : 0.f;
+                        float v3 = (act && b3) ? ET<T>::ld(imb + o3) : 0.f;
+                        float v4 = (act && b4) ? ET<T>::ld(imb + o4) : 0.f;
+                        float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                        float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                        if (!BWD) {
+                            col += val * mk;
+                        } else if (act) {
+                            float tg = go * mk;
+                            float* gib = a.gin + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
+                            if (b1) atomicAdd(gib + o1, w1 * tg);
+                            if (b2) atomicAdd(gib + o2, w2 * tg);
+                            if (b3) atomicAdd(gib + o3, w3 * tg);
+                            if (b4) atomicAdd(gib + o4, w4 * tg);
+                            float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
+                            float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
+                            gmask = go * val;
+                            goffw = a.scale * gww * tg;
+                            goffh = a.scale * ghw * tg;
+                        }
+                    }
+                    if (BWD) {
+                        // every lane of the wave takes part in the butterflies (uniform control flow)
+                        gmask = seg_sum(gmask, a.seg);
+                        goffw = seg_sum(goffw, a.seg);
+                        goffh = seg_sum(goffh, a.seg);
+                        if (live && cl == 0) {
+                            float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + 2 * k;
+                            float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P + k;
+                            if (c0 == 0) { gof[0] = goffw; gof[1] = goffh; gmk[0] = gmask; }
+                            else { gof[0] += goffw; gof[1] += goffh; gmk[0] += gmask; }
+                        }
+                    }
+                }
+            if (!BWD && act) ET<T>::st((T*)a.out + (size_t)pix * C + g * a.Gc + c, col);
+        }
+    }
+}
+
+static int fill_args(DcnArgs& a, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                     int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
+                     int N, int H_in, int W_in, int H_out, int W_out) {
+    YDL_CHECK(kernel_h > 0 && kernel_w > 0 && stride_h > 0 && stride_w > 0 && group > 0 && group_channels > 0, "bad geometry");
+    YDL_CHECK(H_out == (H_in + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1 &&
+              W_out == (W_in + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) / stride_w + 1, "output size mismatch");
+    a.kh = kernel_h; a.kw = kernel_w; a.sh = stride_h; a.sw = stride_w; a.ph = pad_h; a.pw = pad_w;
+    a.dh = dilation_h; a.dw = dilation_w; a.G = group; a.Gc = group_channels; a.scale = offset_scale;
+    a.N = N; a.H = H_in; a.W = W_in; a.Ho = H_out; a.Wo = W_out;
+    int seg = 1;
+    while (seg < group_channels && seg < 64) seg <<= 1;
+    a.seg = seg;
+    a.items = (long long)N * H_out * W_out * group;
+    return 0;
+}
+
+static inline int dcn_grid(const DcnArgs& a) {
+    long long rounds = (a.items + (64 / a.seg) - 1) / (64 / a.seg);
+    long long blocks = (rounds + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" int ydl_dcnv3_fwd(int dtype, const void* input, const void* offset, const void* mask, void* output,
+                             int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                             int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
+                             int N, int H_in, int W_in, int H_out, int W_out, void* stream) {
+    YDL_CHECK(input && offset && mask && output, "null pointer");
+    DcnArgs a{};
+    if (int e = fill_args(a, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+                          group_channels, offset_scale, N, H_in, W_in, H_out, W_out)) return e;
+    a.in = input; a.off = offset; a.msk = mask; a.out = output;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) dcnv3_kernel<float, false><<<dcn_grid(a), 256, 0, st>>>(a);
+    else dcnv3_kernel<bf16_t, false><<<dcn_grid(a), 256, 0, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, const void* mask, const void* grad_output,
+                             float* grad_input, float* grad_offset, float* grad_mask,
+                             int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                             int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
+                             int N, int H_in, int W_in, int H_out, int W_out, void* stream) {
+    YDL_CHECK(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, "null pointer");
+    DcnArgs a{};
+    if (int e = fill_args(a, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+                          group_channels, offset_scale, N, H_in, W_in, H_out, W_out)) return e;
+    a.in = input; a.off = offset; a.msk = mask; a.gout = grad_output;
+    a.gin = grad_input; a.goff = grad_offset; a.gmsk = grad_mask;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) dcnv3_kernel<float, true><<<dcn_grid(a), 256, 0, st>>>(a);
+    else dcnv3_kernel<bf16_t, true><<<dcn_grid(a), 256, 0, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,627 @@
+// Implicit-GEMM convolution on MFMA for gfx950: forward, dgrad (same kernel, different tap tables) and wgrad.
+//
+// Data layout: activations NHWC (pixel stride ld), weights KRSC [Cout][taps][Kc] (K contiguous).
+// GEMM view (forward):  Y[cout][pixel] = sum_k W[cout][k] * X[k][pixel],  k = (tap, cin) flattened.
+// The MFMA "A" operand is the weight tile (rows = cout) and the "B" operand the gathered activation tile
+// (cols = pixels), so a lane's 4 accumulator registers are 4 consecutive output channels of ONE pixel:
+// the epilogue stores 8 B (bf16) / 16 B (f32) per lane straight into NHWC rows.
+//
+// Both element types share one byte geometry: a K-step is 128 bytes per row (64 bf16 / 32 f32), moved as
+// eight 16-byte chunks; an LDS row is 128+16 bytes (one access-width pad => conflict-free ds_read_b128).
+// bf16: v_mfma_f32_16x16x32_bf16, lane reads 8 consecutive k.  f32: 4 x v_mfma_f32_16x16x4_f32 on the 4
+// floats of the same 16-byte read (k permuted identically for both operands; exact f32 fmaf chains).
+#include "common.h"
+
+#define ROWB 144      // LDS row stride in bytes (128 data + 16 pad)
+#define MAXTAPS 64
+
+struct IgemmArgs {
+    const void* A;    // gathered activations (x for fwd, dy for dgrad)
+    const void* B;    // weights [rowsB][Ttot][Kc]
+    void* C;          // output activations
+    float* stats;     // optional BN partials [gridM][2][stats_ld]
+    int N, Hi, Wi, lda;
+    int Kc;           // K elements per tap (channel count of A padded to a chunk multiple)
+    int Ho, Wo, ldc;  // output tensor
+    int Cout;         // logical output channels (rows of B that exist)
+    int Cst;          // channels stored (>= Cout, zero filled beyond Cout)
+    int Hg, Wg;       // output grid points per image handled by this launch
+    int in_mul, out_mul, out_h0, out_w0;
+    int ntaps, Ttot;
+    int accumulate;
+    int M;            // N*Hg*Wg
+    int stats_ld;
+    signed char dh[MAXTAPS], dw[MAXTAPS];
+    unsigned char wt[MAXTAPS];
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// BM = pixel tile (64 or 128), BN = output-channel tile (16, 64 or 128).  256 threads = 4 waves, each wave
+// owns BM/4 pixels x all BN channels.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+    constexpr int V = ET<T>::V;
+    constexpr int AR = BM / 32;                 // A rows per thread
+    constexpr int BR = (BN + 31) / 32;          // B rows per thread
+    constexpr int CT = BN / 16;                 // cout tiles per wave
+    constexpr int PT = BM / 64;                 // pixel tiles per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                           // [2][BM][ROWB]
+    unsigned char* sB = smem + 2 * BM * ROWB;           // [2][BN][ROWB]
+    int* sTap = (int*)(smem + 2 * (BM + BN) * ROWB);    // [MAXTAPS] packed dh | dw<<8 | wt<<16
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    if (t < MAXTAPS) {
+        int v = 0;
+        if (t < p.ntaps) v = ((int)(unsigned char)p.dh[t]) | (((int)(unsigned char)p.dw[t]) << 8) | (((int)p.wt[t]) << 16);
+        sTap[t] = v;
+    }
+
+    // per-thread loader geometry
+    const int q = t & 7;        // chunk column
+    const int r = t >> 3;       // row 0..31
+    int ih0[AR], iw0[AR], nb[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int m = m0 + r + 32 * i;
+        if (m < p.M) {
+            int gw = m % p.Wg;
+            int tmp = m / p.Wg;
+            int gh = tmp % p.Hg;
+            int n = tmp / p.Hg;
+            ih0[i] = gh * p.in_mul;
+            iw0[i] = gw * p.in_mul;
+            nb[i] = n * p.Hi;
+        } else {
+            ih0[i] = -100000; iw0[i] = 0; nb[i] = 0;   // always out of range => zeros
+        }
+    }
+    const int cpt = p.Kc / V;                       // chunks per tap
+    const int nchunks = p.ntaps * cpt;
+    const int nk = (nchunks + 7) >> 3;
+    const size_t browstride = (size_t)p.Ttot * p.Kc;
+    const T* Ag = (const T*)p.A;
+    const T* Bg = (const T*)p.B;
+
+    uint4 ra[AR], rb[BR];
+    __syncthreads();   // sTap visible
+
+    auto gload = [&](int kk) {
+        int Q = kk * 8 + q;
+        int tap = Q / cpt;
+        int cc = (Q - tap * cpt) * V;
+        bool tv = Q < nchunks;
+        int tp = tv ? sTap[tap] : 0;
+        int dh = (int)(signed char)(tp & 0xff), dw = (int)(signed char)((tp >> 8) & 0xff), wt = (tp >> 16) & 0xff;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int ih = ih0[i] + dh, iw = iw0[i] + dw;
+            bool ok = tv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *(const uint4*)(Ag + ((size_t)(nb[i] + ih) * p.Wi + iw) * p.lda + cc);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            int row = r + 32 * i;
+            int co = n0 + row;
+            bool ok = tv && row < BN && co < p.Cout;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *(const uint4*)(Bg + (size_t)co * browstride + (size_t)wt * p.Kc + cc);
+            rb[i] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *(uint4*)(sA + (size_t)buf * BM * ROWB + (r + 32 * i) * ROWB + q * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            int row = r + 32 * i;
+            if (row < BN) *(uint4*)(sB + (size_t)buf * BN * ROWB + row * ROWB + q * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    const int lrow = lane & 15, lk = (lane >> 4) * 16;
+    for (int kk = 0; kk < nk; ++kk) {
+        if (kk + 1 < nk) gload(kk + 1);
+        const unsigned char* a_base = sB + (size_t)cur * BN * ROWB + lrow * ROWB + lk;
+        const unsigned char* b_base = sA + (size_t)cur * BM * ROWB + (wave * (BM / 4) + lrow) * ROWB + lk;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 af[CT], bfr[PT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * ROWB + s * 64);
+#pragma unroll
+            for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * ROWB + s * 64);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+        }
+        if (kk + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------- epilogue: store ----------------
+    T* Cg = (T*)p.C;
+    const int cq = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        int m = m0 + wave * (BM / 4) + j * 16 + lrow;
+        if (m < p.M) {
+            int gw = m % p.Wg;
+            int tmp = m / p.Wg;
+            int gh = tmp % p.Hg;
+            int n = tmp / p.Hg;
+            size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + p.out_h0)) * p.Wo + (gw * p.out_mul + p.out_w0);
+            T* dst = Cg + pix * p.ldc;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                int co = n0 + c * 16 + cq;
+                if (co + 3 < p.Cst) {
+                    float v[4] = {acc[c][j][0], acc[c][j][1], acc[c][j][2], acc[c][j][3]};
+                    if constexpr (sizeof(T) == 4) {
+                        float4* d4 = (float4*)(dst + co);
+                        if (p.accumulate) { float4 o = *d4; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                        *d4 = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2* d2 = (uint2*)(dst + co);
+                        if (p.accumulate) {
+                            uint2 o = *d2;
+                            v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+                            v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+                        }
+                        uint2 u;
+                        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                        *d2 = u;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Cst) {
+                            float v = acc[c][j][e];
+                            if (p.accumulate) v += ET<T>::ld(dst + co + e);
+                            ET<T>::st(dst + co + e, v);
+                        }
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue: BN partial statistics (block-local two-pass => Chan-mergeable) ----------
+    if (p.stats != nullptr) {
+        float* red = (float*)smem;             // [4][BN]; safe: all LDS reads finished at the last barrier
+        float* smean = red + 4 * BN;           // [BN]
+        const int nvalid = min(BM, p.M - m0);
+        float s[CT][4];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) v += acc[c][j][e];   // rows beyond M are exact zeros
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                s[c][e] = v;
+            }
+        if (lrow == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave * BN + c * 16 + cq + e] = s[c][e];
+        }
+        __syncthreads();
+        float tot = 0.f;
+        if (t < BN) {
+            tot = red[t] + red[BN + t] + red[2 * BN + t] + red[3 * BN + t];
+            smean[t] = tot / (float)nvalid;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float mu = smean[c * 16 + cq + e];
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {
+                    int m = m0 + wave * (BM / 4) + j * 16 + lrow;
+                    float d = acc[c][j][e] - mu;
+                    v += (m < p.M) ? d * d : 0.f;
+                }
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                s[c][e] = v;
+            }
+        __syncthreads();   // everyone has read smean/red before red is overwritten
+        if (lrow == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave * BN + c * 16 + cq + e] = s[c][e];
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < p.Cout) {
+            float m2 = red[t] + red[BN + t] + red[2 * BN + t] + red[3 * BN + t];
+            float* dst = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld;
+            dst[n0 + t] = tot;
+            dst[p.stats_ld + n0 + t] = m2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN>
+static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
+    dim3 grid((a.M + BM - 1) / BM, (a.Cst + BN - 1) / BN);
+    size_t smem = 2 * (BM + BN) * ROWB + MAXTAPS * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    igemm_kernel<T, BM, BN><<<grid, 256, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+struct TileCfg { int BM, BN; };
+static TileCfg pick_cfg(int M, int Cst) {
+    TileCfg c;
+    c.BN = Cst <= 16 ? 16 : (Cst <= 64 ? 64 : 128);
+    c.BM = 128;
+    // small-M layers: shrink the pixel tile so that the grid still covers the 256 CUs a few times
+    long blocks = (long)((M + 127) / 128) * ((Cst + c.BN - 1) / c.BN);
+    if (blocks < 512 && c.BN != 16) c.BM = 64;
+    if (c.BM == 64 && c.BN == 128) {
+        long b2 = (long)((M + 63) / 64) * ((Cst + 127) / 128);
+        if (b2 < 512) c.BN = 64;
+    }
+    return c;
+}
+
+template <typename T>
+static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = nullptr, int force_bm = 0) {
+    TileCfg c = pick_cfg(a.M, a.Cst);
+    if (force_bm) c.BM = force_bm;
+    if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
+    if (c.BM == 128 && c.BN == 128) return launch_igemm<T, 128, 128>(a, st);
+    if (c.BM == 128 && c.BN == 64) return launch_igemm<T, 128, 64>(a, st);
+    if (c.BM == 128 && c.BN == 16) return launch_igemm<T, 128, 16>(a, st);
+    if (c.BM == 64 && c.BN == 128) return launch_igemm<T, 64, 128>(a, st);
+    if (c.BM == 64 && c.BN == 64) return launch_igemm<T, 64, 64>(a, st);
+    return launch_igemm<T, 64, 16>(a, st);
+}
+
+static int check_geom(const ydl_conv_geom* g, int dtype) {
+    YDL_CHECK(g != nullptr, "null geometry");
+    YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16, "bad dtype");
+    YDL_CHECK(g->N > 0 && g->Hi > 0 && g->Wi > 0 && g->Cin > 0 && g->Cout > 0, "non-positive dims");
+    YDL_CHECK(g->k >= 1 && g->k * g->k <= MAXTAPS && g->s >= 1 && g->p >= 0, "unsupported kernel/stride/pad");
+    YDL_CHECK(g->Ho == (g->Hi + 2 * g->p - g->k) / g->s + 1 && g->Wo == (g->Wi + 2 * g->p - g->k) / g->s + 1,
+              "output size does not match (H+2p-k)/s+1");
+    int es = esize(dtype);
+    YDL_CHECK(g->ldx >= round_up(g->Cin, 8) && g->ldy >= g->Cout, "pixel stride smaller than channel count");
+    YDL_CHECK((g->ldx * es) % 16 == 0 && (g->ldy * es) % 16 == 0, "pixel strides must be 16-byte multiples");
+    YDL_CHECK((int64_t)g->N * g->Hi * g->Wi < (1ll << 31) && (int64_t)g->N * g->Ho * g->Wo < (1ll << 31), "too many pixels");
+    return 0;
+}
+
+// number of M-blocks the forward launch will use (needed by the caller to size/consume the stats partials)
+static int fwd_grid_m(const ydl_conv_geom* g) {
+    int M = g->N * g->Ho * g->Wo;
+    int Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
+    TileCfg c = pick_cfg(M, Cst);
+    return (M + c.BM - 1) / c.BM;
+}
+
+extern "C" int64_t ydl_conv_fwd_stats_ws_bytes(const ydl_conv_geom* g, int dtype) {
+    (void)dtype;
+    // [gridM][2][round_up(Cout,8)] floats + room for ydl_bn_finalize's level-1 chunk partials (gridM/64 + 1 rows)
+    int64_t gm = fwd_grid_m(g);
+    return (gm + gm / 64 + 2) * 2 * round_up(g->Cout, 8) * (int64_t)sizeof(float);
+}
+extern "C" int ydl_conv_fwd_grid_m(const ydl_conv_geom* g) { return fwd_grid_m(g); }
+extern "C" int ydl_conv_fwd_block_m(const ydl_conv_geom* g) {
+    int M = g->N * g->Ho * g->Wo;
+    int Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
+    return pick_cfg(M, Cst).BM;
+}
+
+extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
+                            float* stats_ws, void* stream) {
+    if (int e = check_geom(g, dtype)) return e;
+    YDL_CHECK(aligned16(x) && aligned16(w) && aligned16(y), "pointers must be 16-byte aligned");
+    IgemmArgs a{};
+    a.A = x; a.B = w; a.C = y; a.stats = stats_ws;
+    a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.lda = g->ldx;
+    a.Kc = round_up(g->Cin, 8);
+    a.Ho = g->Ho; a.Wo = g->Wo; a.ldc = g->ldy; a.Cout = g->Cout;
+    a.Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
+    a.Hg = g->Ho; a.Wg = g->Wo; a.in_mul = g->s; a.out_mul = 1; a.out_h0 = 0; a.out_w0 = 0;
+    a.ntaps = g->k * g->k; a.Ttot = a.ntaps; a.accumulate = 0;
+    a.M = g->N * g->Ho * g->Wo;
+    a.stats_ld = round_up(g->Cout, 8);
+    for (int r = 0; r < g->k; ++r)
+        for (int s = 0; s < g->k; ++s) {
+            int tpi = r * g->k + s;
+            a.dh[tpi] = (signed char)(r - g->p); a.dw[tpi] = (signed char)(s - g->p); a.wt[tpi] = (unsigned char)tpi;
+        }
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
+}
+
+extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
+                              int accumulate, void* stream) {
+    if (int e = check_geom(g, dtype)) return e;
+    YDL_CHECK(aligned16(dy) && aligned16(wt) && aligned16(dx), "pointers must be 16-byte aligned");
+    YDL_CHECK(g->ldy >= round_up(g->Cout, 8), "dy pixel stride must cover Cout rounded up to 8");
+    hipStream_t st = (hipStream_t)stream;
+    const int s = g->s, k = g->k, pd = g->p;
+    for (int ph = 0; ph < s; ++ph)
+        for (int pw = 0; pw < s; ++pw) {
+            IgemmArgs a{};
+            a.A = dy; a.B = wt; a.C = dx; a.stats = nullptr;
+            a.N = g->N; a.Hi = g->Ho; a.Wi = g->Wo; a.lda = g->ldy;
+            a.Kc = round_up(g->Cout, 8);
+            a.Ho = g->Hi; a.Wo = g->Wi; a.ldc = g->ldx; a.Cout = g->Cin;
+            a.Cst = g->Cin;
+            a.Hg = (g->Hi - ph + s - 1) / s; a.Wg = (g->Wi - pw + s - 1) / s;
+            if (a.Hg <= 0 || a.Wg <= 0) continue;
+            a.in_mul = 1; a.out_mul = s; a.out_h0 = ph; a.out_w0 = pw;
+            a.Ttot = k * k; a.accumulate = accumulate;
+            a.M = g->N * a.Hg * a.Wg;
+            int nt = 0;
+            // dx[h] gets dy[(h + p - r)/s] * w[r] for taps r with (h + p - r) % s == 0
+            for (int r = 0; r < k; ++r) {
+                int nh = ph + pd - r;
+                if (((nh % s) + s) % s != 0) continue;
+                for (int c = 0; c < k; ++c) {
+                    int nw = pw + pd - c;
+                    if (((nw % s) + s) % s != 0) continue;
+                    int dh = nh >= 0 ? nh / s : -((-nh) / s), dw = nw >= 0 ? nw / s : -((-nw) / s);
+                    a.dh[nt] = (signed char)dh; a.dw[nt] = (signed char)dw; a.wt[nt] = (unsigned char)(r * k + c);
+                    ++nt;
+                }
+            }
+            a.ntaps = nt;
+            int e = 0;
+            if (nt == 0) {
+                // no tap reaches this parity class (k < s): the gradient there is zero
+                a.ntaps = 0;
+            }
+            e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
+            if (e) return e;
+        }
+    return 0;
+}
+
+// ======================================================================================================
+// wgrad: dW[cout][j] += sum_pixels dY[pixel][cout] * Xcol[pixel][j],   j = (tap, cin) flattened
+// Tiles: 128 bytes of cout x 128 bytes of j (64x64 bf16 / 32x32 f32), 64 pixels per stage, split-K over
+// pixels (gridDim.z), f32 atomics into dW.  bf16 operands are transposed on the LDS read path by
+// ds_read_b64_tr_b16 (the contraction index = pixel is the row index of both NHWC tiles).
+// ======================================================================================================
+struct WgradArgs {
+    const void* X; const void* dY; float* dW;
+    int N, Hi, Wi, ldx, Kc;       // Kc = padded Cin
+    int Ho, Wo, ldy, Cout;
+    int k, s, p;
+    int M;                        // N*Ho*Wo
+    int chunk;                    // pixels per split (multiple of 64)
+    int ntaps;
+};
+
+#define WG_BKP 64
+
+// TR = true: bf16 fragments via ds_read_b64_tr_b16; false: eight scalar LDS reads per fragment (debug/reference)
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    constexpr int V = ET<T>::V;
+    constexpr int TE = 128 / sizeof(T);        // elements per 128-byte tile row: 64 bf16 / 32 f32
+    __shared__ __attribute__((aligned(16))) unsigned char sY[WG_BKP * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sX[WG_BKP * ROWB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wi = wave >> 1, wj = wave & 1;   // wave grid over (cout, j)
+    const int jt = blockIdx.x, ct = blockIdx.y;
+    const int q = t & 7, r = t >> 3;
+    const int cpt = p.Kc / V;
+    const int nchunks = p.ntaps * cpt;
+    // this thread's X chunk is fixed for the whole kernel
+    const int Q = jt * 8 + q;
+    const bool qv = Q < nchunks;
+    const int tap = qv ? Q / cpt : 0;
+    const int cc = (Q - tap * cpt) * V;
+    const int dh = tap / p.k - p.p, dw = tap % p.k - p.p;
+    const int co_chunk = ct * TE + q * V;          // first cout of this thread's dY chunk
+    const bool yv = co_chunk < p.Cout;             // Cout % V may be != 0: tail handled by ldy padding zeros
+    const T* Xg = (const T*)p.X;
+    const T* Yg = (const T*)p.dY;
+    const int pbeg = blockIdx.z * p.chunk;
+    const int pend = min(p.M, pbeg + p.chunk);
+
+    constexpr int NT = (sizeof(T) == 2) ? 2 : 1;   // 16x16 tiles per wave per dim
+    f32x4 acc[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int HoWo = p.Ho * p.Wo;
+    for (int p0 = pbeg; p0 < pend; p0 += WG_BKP) {
+        uint4 vy[2], vx[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = p0 + r + 32 * i;
+            vy[i] = make_uint4(0, 0, 0, 0);
+            vx[i] = make_uint4(0, 0, 0, 0);
+            if (m < pend) {
+                if (yv) vy[i] = *(const uint4*)(Yg + (size_t)m * p.ldy + co_chunk);
+                if (qv) {
+                    int n = m / HoWo;
+                    int rem = m - n * HoWo;
+                    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    int ih = ho * p.s + dh, iw = wo * p.s + dw;
+                    if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+                        vx[i] = *(const uint4*)(Xg + ((size_t)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc);
+                }
+            }
+        }
+        __syncthreads();   // previous stage's LDS reads done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(uint4*)(sY + (r + 32 * i) * ROWB + q * 16) = vy[i];
+            *(uint4*)(sX + (r + 32 * i) * ROWB + q * 16) = vx[i];
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 2 && !TR) {
+            const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[NT], bfv[NT];
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    unsigned short e[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        e[x] = *(const unsigned short*)(sY + (ks * 32 + g * 8 + x) * ROWB + (wi * 32 + a * 16 + li) * 2);
+                    af[a] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    unsigned short e[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        e[x] = *(const unsigned short*)(sX + (ks * 32 + g * 8 + x) * ROWB + (wj * 32 + b * 16 + li) * 2);
+                    bfv[b] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) Mma<bf16_t>::run(af[a], bfv[b], acc[a][b]);
+            }
+        } else if constexpr (sizeof(T) == 2) {
+            // group g = lane>>4 covers pixels 8g..8g+7 of a 32-pixel k-step; lane 4q'+p' of the group addresses
+            // row q' (pixel), columns 4p'..4p'+3 (channels); result element e = pixel row e, channel = lane&15.
+            const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[NT], bfv[NT];
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const unsigned char* base = sY + (ks * 32 + g * 8 + lq) * ROWB + (wi * 32 + a * 16 + lp * 4) * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROWB));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    af[a] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const unsigned char* base = sX + (ks * 32 + g * 8 + lq) * ROWB + (wj * 32 + b * 16 + lp * 4) * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROWB));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    bfv[b] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) Mma<bf16_t>::run(af[a], bfv[b], acc[a][b]);
+            }
+        } else {
+            // f32: A[i = lane&15][k = lane>>4] = dY[pixel k][cout i]; one float per lane per MFMA (k = 4 pixels)
+            const int li = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+            for (int ks = 0; ks < WG_BKP / 4; ++ks) {
+                float a = *(const float*)(sY + (ks * 4 + lk) * ROWB + (wi * 16 + li) * 4);
+                float b = *(const float*)(sX + (ks * 4 + lk) * ROWB + (wj * 16 + li) * 4);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[0][0], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: D[row = cout][col = j]; lane holds col = lane&15, rows (lane>>4)*4 + e
+    constexpr int SUB = (sizeof(T) == 2) ? 32 : 16;
+    const size_t wrow = (size_t)p.ntaps * p.Kc;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            int j = jt * TE + wj * SUB + b * 16 + (lane & 15);
+            if (j < (int)wrow) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int co = ct * TE + wi * SUB + a * 16 + (lane >> 4) * 4 + e;
+                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * wrow + j, acc[a][b][e]);
+                }
+            }
+        }
+}
+
+static int g_wgrad_tr = 1;
+// debug knobs (tests A/B the transposed-read path against the scalar-read path): key 0 = wgrad tr-read on/off
+extern "C" void ydl_debug_set(int key, int val) { if (key == 0) g_wgrad_tr = val; }
+
+extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream) {
+    if (int e = check_geom(g, dtype)) return e;
+    YDL_CHECK(aligned16(x) && aligned16(dy) && aligned16(dw), "pointers must be 16-byte aligned");
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    YDL_CHECK(g->ldy >= round_up(g->Cout, V), "dy pixel stride must cover Cout rounded up to a 16-byte chunk");
+    WgradArgs a{};
+    a.X = x; a.dY = dy; a.dW = dw;
+    a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = round_up(g->Cin, 8);
+    a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
+    a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = g->k * g->k;
+    a.M = g->N * g->Ho * g->Wo;
+    const int TE = dtype == YDL_F32 ? 32 : 64;
+    int jtiles = (a.ntaps * a.Kc + TE - 1) / TE;
+    int ctiles = (g->Cout + TE - 1) / TE;
+    // split pixels so that the grid has ~2048 blocks, each with at least 4 stages
+    long tiles = (long)jtiles * ctiles;
+    int stages = (a.M + WG_BKP - 1) / WG_BKP;
+    int splits = (int)((2048 + tiles - 1) / tiles);
+    if (splits > stages / 4) splits = stages / 4;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    int per = (stages + splits - 1) / splits;
+    a.chunk = per * WG_BKP;
+    splits = (a.M + a.chunk - 1) / a.chunk;
+    dim3 grid(jtiles, ctiles, splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) wgrad_kernel<float, false><<<grid, 256, 0, st>>>(a);
+    else if (g_wgrad_tr) wgrad_kernel<bf16_t, true><<<grid, 256, 0, st>>>(a);
+    else wgrad_kernel<bf16_t, false><<<grid, 256, 0, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

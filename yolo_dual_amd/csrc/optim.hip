@@ -1,0 +1,105 @@
+// Weight re-layout (f32 KRSC master -> compute copies), wgrad un-padding, and the fused SGD(nesterov)+EMA step
+// over flat arenas (utils/torch_utils.py:318-346 smart_optimizer groups, :404-428 ModelEMA.update).
+#include "common.h"
+
+// w[co][t][ci_p] = master[co][t][ci] (zero pad);  wt[ci][t][co_p] = master[co][t][ci]
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ master, T* __restrict__ w, T* __restrict__ wt,
+                                                          int Cout, int kk, int Cin, int Cin_p, int Cout_p) {
+    const long long n1 = (long long)Cout * kk * Cin_p;
+    const long long n2 = (long long)Cin * kk * Cout_p;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            if (w == nullptr) continue;
+            int ci = (int)(i % Cin_p);
+            long long r = i / Cin_p;           // co*kk + t
+            float v = ci < Cin ? master[r * Cin + ci] : 0.f;
+            ET<T>::st(w + i, v);
+        } else {
+            if (wt == nullptr) continue;
+            long long j = i - n1;
+            int co = (int)(j % Cout_p);
+            long long r = j / Cout_p;          // ci*kk + t
+            int t = (int)(r % kk);
+            int ci = (int)(r / kk);
+            float v = co < Cout ? master[((long long)co * kk + t) * Cin + ci] : 0.f;
+            ET<T>::st(wt + j, v);
+        }
+    }
+}
+
+extern "C" int ydl_weight_prep(int dtype, const float* master, void* w, void* wt, int Cout, int kk, int Cin, void* stream) {
+    YDL_CHECK(master && (w || wt) && Cout > 0 && kk > 0 && Cin > 0, "bad arguments");
+    int Cin_p = round_up(Cin, 8), Cout_p = round_up(Cout, 8);
+    long long total = (long long)Cout * kk * Cin_p + (long long)Cin * kk * Cout_p;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) weight_prep_kernel<float><<<grid, 256, 0, st>>>(master, (float*)w, (float*)wt, Cout, kk, Cin, Cin_p, Cout_p);
+    else weight_prep_kernel<bf16_t><<<grid, 256, 0, st>>>(master, (bf16_t*)w, (bf16_t*)wt, Cout, kk, Cin, Cin_p, Cout_p);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void wgrad_unpad_kernel(const float* __restrict__ dw, float* __restrict__ grad, long long rows, int Cin, int Cin_p, int accumulate) {
+    const long long total = rows * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i / Cin;
+        int c = (int)(i - r * Cin);
+        float v = dw[r * Cin_p + c];
+        grad[i] = accumulate ? grad[i] + v : v;
+    }
+}
+extern "C" int ydl_wgrad_unpad(const float* dw, float* grad, int Cout, int kk, int Cin, int accumulate, void* stream) {
+    YDL_CHECK(dw && grad, "null pointer");
+    long long rows = (long long)Cout * kk;
+    long long total = rows * Cin;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    wgrad_unpad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dw, grad, rows, Cin, round_up(Cin, 8), accumulate);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// One pass over [params | buffers]: SGD-nesterov on params (two lr/decay groups), EMA on everything.
+//   g = grad*grad_scale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*(g + mom*buf) ; ema = d*ema + (1-d)*p
+__global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                                      float* __restrict__ mombuf, float* __restrict__ ema,
+                                                      long long n_decay, long long n_params, long long n_total,
+                                                      float lr0, float lr1, float mom, float wd, float gscale, int first, float d) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (long long)gridDim.x * blockDim.x) {
+        float p = params[i];
+        if (i < n_params) {
+            bool dec = i < n_decay;
+            float g = grads[i] * gscale;
+            if (dec && wd != 0.f) g = g + wd * p;
+            float b = first ? g : mom * mombuf[i] + g;
+            mombuf[i] = b;
+            float upd = g + mom * b;
+            p = p - (dec ? lr0 : lr1) * upd;
+            params[i] = p;
+        }
+        if (d >= 0.f && ema != nullptr) {
+            float e = ema[i];
+            e = e * d;
+            e = e + (1.f - d) * p;
+            ema[i] = e;
+        }
+    }
+}
+
+extern "C" int ydl_sgd_ema_step(float* params, const float* grads, float* momentum, float* ema,
+                                int64_t n_decay, int64_t n_params, int64_t n_total,
+                                float lr_decay_group, float lr_nodecay_group, float mom, float weight_decay, float grad_scale,
+                                int first_step, float ema_decay, void* stream) {
+    YDL_CHECK(params && grads && momentum, "null pointer");
+    YDL_CHECK(0 <= n_decay && n_decay <= n_params && n_params <= n_total, "bad arena partition");
+    int grid = (int)((n_total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    sgd_ema_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, momentum, ema, n_decay, n_params, n_total,
+                                                           lr_decay_group, lr_nodecay_group, mom, weight_decay, grad_scale,
+                                                           first_step, ema_decay);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,423 @@
+// Spatial NHWC ops: max-pool, nearest / bilinear resize (both align_corners conventions), strided slice copy,
+// NCHW<->NHWC edge conversion, per-(n,c) channel gating.  HBM-bound, 16-byte channel vectors per thread.
+// Index arithmetic restates ATen's (UpSample.h area_pixel_compute_source_index / nearest_idx) with explicit
+// round-to-nearest f32 ops so the compiler cannot contract them into FMAs: indices are bit-exact vs the CPU.
+#include "common.h"
+
+static inline int sgrid(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// max pool
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                          uint8_t* __restrict__ idx, int N, int Hi, int Wi, int Ho, int Wo,
+                                                          int Cp, int k, int s, int p) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = (long long)N * Ho * Wo * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int cq = (int)(i % cpp);
+        long long pix = i / cpp;
+        int wo = (int)(pix % Wo);
+        long long t2 = pix / Wo;
+        int ho = (int)(t2 % Ho);
+        int n = (int)(t2 / Ho);
+        float best[V];
+        int bi[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        bool first = true;
+        for (int ky = 0; ky < k; ++ky) {
+            int ih = ho * s - p + ky;
+            if ((unsigned)ih >= (unsigned)Hi) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                int iw = wo * s - p + kx;
+                if ((unsigned)iw >= (unsigned)Wi) continue;
+                float v[V];
+                unpack16<T>(*(const uint4*)(x + ((size_t)(n * Hi + ih) * Wi + iw) * ldx + cq * V), v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    // ATen: update when (val > max) || isnan(val); first valid element initialises
+                    if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = ky * k + kx; }
+                }
+                first = false;
+            }
+        }
+        *(uint4*)(y + (size_t)pix * ldy + cq * V) = pack16<T>(best);
+        if (idx) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) idx[(size_t)pix * Cp + cq * V + e] = (uint8_t)bi[e];
+        }
+    }
+}
+
+// gather formulation: every input element collects dy from the (<= ceil(k/s)^2) windows whose arg-max it is
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx,
+                                                          T* __restrict__ dx, int lddx, int accumulate, int N, int Hi, int Wi,
+                                                          int Ho, int Wo, int Cp, int k, int s, int p) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = (long long)N * Hi * Wi * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int cq = (int)(i % cpp);
+        long long pix = i / cpp;
+        int iw = (int)(pix % Wi);
+        long long t2 = pix / Wi;
+        int ih = (int)(t2 % Hi);
+        int n = (int)(t2 / Hi);
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = 0.f;
+        if (accumulate) unpack16<T>(*(const uint4*)(dx + (size_t)pix * lddx + cq * V), g);
+        for (int ky = 0; ky < k; ++ky) {
+            int nh = ih + p - ky;
+            if (nh < 0 || nh % s != 0) continue;
+            int ho = nh / s;
+            if (ho >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                int nw = iw + p - kx;
+                if (nw < 0 || nw % s != 0) continue;
+                int wo = nw / s;
+                if (wo >= Wo) continue;
+                size_t op = ((size_t)(n * Ho + ho) * Wo + wo);
+                float d[V];
+                unpack16<T>(*(const uint4*)(dy + op * lddy + cq * V), d);
+                const uint8_t* ip = idx + op * Cp + cq * V;
+                int code = ky * k + kx;
+#pragma unroll
+                for (int e = 0; e < V; ++e) g[e] += (ip[e] == code) ? d[e] : 0.f;
+            }
+        }
+        *(uint4*)(dx + (size_t)pix * lddx + cq * V) = pack16<T>(g);
+    }
+}
+
+extern "C" int ydl_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int ldy, uint8_t* idx,
+                               int N, int Hi, int Wi, int Ho, int Wo, int C, int k, int s, int p, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(x && y && ldx >= Cp && ldy >= Cp && k * k <= 255, "bad arguments");
+    YDL_CHECK(Ho == (Hi + 2 * p - k) / s + 1 && Wo == (Wi + 2 * p - k) / s + 1, "output size mismatch");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = sgrid((long long)N * Ho * Wo * (Cp / V));
+    if (dtype == YDL_F32) maxpool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, ldx, (float*)y, ldy, idx, N, Hi, Wi, Ho, Wo, Cp, k, s, p);
+    else maxpool_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, (bf16_t*)y, ldy, idx, N, Hi, Wi, Ho, Wo, Cp, k, s, p);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ydl_maxpool_bwd(int dtype, const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, int accumulate,
+                               int N, int Hi, int Wi, int Ho, int Wo, int C, int k, int s, int p, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(dy && dx && idx && lddy >= Cp && lddx >= Cp, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = sgrid((long long)N * Hi * Wi * (Cp / V));
+    if (dtype == YDL_F32) maxpool_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)dy, lddy, idx, (float*)dx, lddx, accumulate, N, Hi, Wi, Ho, Wo, Cp, k, s, p);
+    else maxpool_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)dy, lddy, idx, (bf16_t*)dx, lddx, accumulate, N, Hi, Wi, Ho, Wo, Cp, k, s, p);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// resize
+// ------------------------------------------------------------------------------------------------------
+struct Lin { int i0, i1; float w0, w1; };
+
+// bilinear source index/weights for one axis, ATen semantics (float accscalar)
+__device__ __forceinline__ Lin lin_src(int dst, float scale, int in, bool align) {
+    Lin L;
+    float src;
+    if (align) {
+        src = __fmul_rn(scale, (float)dst);
+    } else {
+        src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
+        if (src < 0.f) src = 0.f;
+    }
+    L.i0 = (int)src;
+    if (L.i0 > in - 1) L.i0 = in - 1;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.w1 = __fsub_rn(src, (float)L.i0);
+    L.w0 = __fsub_rn(1.f, L.w1);
+    return L;
+}
+__device__ __forceinline__ int near_src(int dst, float scale, int in) {
+    int v = (int)floorf(__fmul_rn((float)dst, scale));
+    return v < in - 1 ? v : in - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(int mode, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                         int N, int Hi, int Wi, int Ho, int Wo, int Cp, float sh, float sw) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = (long long)N * Ho * Wo * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int cq = (int)(i % cpp);
+        long long pix = i / cpp;
+        int wo = (int)(pix % Wo);
+        long long t2 = pix / Wo;
+        int ho = (int)(t2 % Ho);
+        int n = (int)(t2 / Ho);
+        const T* xb = x + (size_t)n * Hi * Wi * ldx + cq * V;
+        float o[V];
+        if (mode == 0) {
+            int ih = near_src(ho, sh, Hi), iw = near_src(wo, sw, Wi);
+            *(uint4*)(y + (size_t)pix * ldy + cq * V) = *(const uint4*)(xb + ((size_t)ih * Wi + iw) * ldx);
+            continue;
+        }
+        Lin lh = lin_src(ho, sh, Hi, mode == 2), lw = lin_src(wo, sw, Wi, mode == 2);
+        float v00[V], v01[V], v10[V], v11[V];
+        unpack16<T>(*(const uint4*)(xb + ((size_t)lh.i0 * Wi + lw.i0) * ldx), v00);
+        unpack16<T>(*(const uint4*)(xb + ((size_t)lh.i0 * Wi + lw.i1) * ldx), v01);
+        unpack16<T>(*(const uint4*)(xb + ((size_t)lh.i1 * Wi + lw.i0) * ldx), v10);
+        unpack16<T>(*(const uint4*)(xb + ((size_t)lh.i1 * Wi + lw.i1) * ldx), v11);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            o[e] = lh.w0 * (lw.w0 * v00[e] + lw.w1 * v01[e]) + lh.w1 * (lw.w0 * v10[e] + lw.w1 * v11[e]);
+        *(uint4*)(y + (size_t)pix * ldy + cq * V) = pack16<T>(o);
+    }
+}
+
+// gather backward: an input element (ih, iw) scans the output range that can reference it and re-derives the
+// forward index/weights for each candidate => exactly the transpose of the forward, for any scale.
+__device__ __forceinline__ void cand_range(int i, int in, int out, float scale, int mode, int& lo, int& hi) {
+    // conservative bounds on {dst : src(dst) in (i-1, i+1)}: dst ~ (i +- 1 + 0.5)/scale
+    float inv = scale > 0.f ? 1.0f / scale : (float)out;
+    float a = ((float)i - 1.5f) * inv - 2.f, b = ((float)i + 1.5f) * inv + 2.f;
+    if (mode == 0) { a = (float)i * inv - 2.f; b = ((float)i + 1.f) * inv + 2.f; }
+    lo = a < 0.f ? 0 : (int)a;
+    hi = b > (float)(out - 1) ? out - 1 : (int)b;
+    if (i == in - 1) hi = out - 1;      // clamped tail (nearest min(), bilinear edge clamp)
+    if (i == 0) lo = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(int mode, const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx,
+                                                         int accumulate, int N, int Hi, int Wi, int Ho, int Wo, int Cp, float sh, float sw) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = (long long)N * Hi * Wi * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int cq = (int)(i % cpp);
+        long long pix = i / cpp;
+        int iw = (int)(pix % Wi);
+        long long t2 = pix / Wi;
+        int ih = (int)(t2 % Hi);
+        int n = (int)(t2 / Hi);
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = 0.f;
+        if (accumulate) unpack16<T>(*(const uint4*)(dx + (size_t)pix * lddx + cq * V), g);
+        int hlo, hhi, wlo, whi;
+        cand_range(ih, Hi, Ho, sh, mode, hlo, hhi);
+        cand_range(iw, Wi, Wo, sw, mode, wlo, whi);
+        const T* db = dy + (size_t)n * Ho * Wo * lddy + cq * V;
+        for (int ho = hlo; ho <= hhi; ++ho) {
+            float wh;
+            if (mode == 0) wh = near_src(ho, sh, Hi) == ih ? 1.f : 0.f;
+            else { Lin l = lin_src(ho, sh, Hi, mode == 2); wh = (l.i0 == ih ? l.w0 : 0.f) + (l.i1 == ih ? l.w1 : 0.f); }
+            if (wh == 0.f) continue;
+            for (int wo = wlo; wo <= whi; ++wo) {
+                float ww;
+                if (mode == 0) ww = near_src(wo, sw, Wi) == iw ? 1.f : 0.f;
+                else { Lin l = lin_src(wo, sw, Wi, mode == 2); ww = (l.i0 == iw ? l.w0 : 0.f) + (l.i1 == iw ? l.w1 : 0.f); }
+                if (ww == 0.f) continue;
+                float d[V];
+                unpack16<T>(*(const uint4*)(db + ((size_t)ho * Wo + wo) * lddy), d);
+                float wgt = wh * ww;
+#pragma unroll
+                for (int e = 0; e < V; ++e) g[e] += wgt * d[e];
+            }
+        }
+        *(uint4*)(dx + (size_t)pix * lddx + cq * V) = pack16<T>(g);
+    }
+}
+
+static inline float axis_scale(int mode, int in, int out, float given) {
+    if (mode == 2) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    if (given > 0.f) return given;
+    return (float)in / (float)out;
+}
+
+extern "C" int ydl_resize_fwd(int dtype, int mode, const void* x, int ldx, void* y, int ldy,
+                              int N, int Hi, int Wi, int Ho, int Wo, int C, float scale_h, float scale_w, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(x && y && mode >= 0 && mode <= 2 && ldx >= Cp && ldy >= Cp, "bad arguments");
+    float sh = axis_scale(mode, Hi, Ho, scale_h), sw = axis_scale(mode, Wi, Wo, scale_w);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = sgrid((long long)N * Ho * Wo * (Cp / V));
+    if (dtype == YDL_F32) resize_fwd_kernel<float><<<grid, 256, 0, st>>>(mode, (const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, Ho, Wo, Cp, sh, sw);
+    else resize_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>(mode, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, Hi, Wi, Ho, Wo, Cp, sh, sw);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ydl_resize_bwd(int dtype, int mode, const void* dy, int lddy, void* dx, int lddx, int accumulate,
+                              int N, int Hi, int Wi, int Ho, int Wo, int C, float scale_h, float scale_w, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(dy && dx && mode >= 0 && mode <= 2 && lddy >= Cp && lddx >= Cp, "bad arguments");
+    float sh = axis_scale(mode, Hi, Ho, scale_h), sw = axis_scale(mode, Wi, Wo, scale_w);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = sgrid((long long)N * Hi * Wi * (Cp / V));
+    if (dtype == YDL_F32) resize_bwd_kernel<float><<<grid, 256, 0, st>>>(mode, (const float*)dy, lddy, (float*)dx, lddx, accumulate, N, Hi, Wi, Ho, Wo, Cp, sh, sw);
+    else resize_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(mode, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate, N, Hi, Wi, Ho, Wo, Cp, sh, sw);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// strided slice copy / add
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void copy2d_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd,
+                                                     long long npix, int Cp, int accumulate) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = npix * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pix = i / cpp;
+        int c = (int)(i - pix * cpp) * V;
+        uint4 v = *(const uint4*)(src + pix * lds_ + c);
+        if (accumulate) {
+            float a[V], b[V];
+            unpack16<T>(v, a);
+            unpack16<T>(*(const uint4*)(dst + pix * ldd + c), b);
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[e] += b[e];
+            v = pack16<T>(a);
+        }
+        *(uint4*)(dst + pix * ldd + c) = v;
+    }
+}
+// element-granular fallback for channel slices that are not 16-byte aligned (c0 or C not a chunk multiple)
+template <typename T>
+__global__ __launch_bounds__(256) void copy2d_scalar_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd,
+                                                            long long npix, int C, int accumulate) {
+    const long long total = npix * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pix = i / C;
+        int c = (int)(i - pix * C);
+        float v = ET<T>::ld(src + pix * lds_ + c);
+        if (accumulate) v += ET<T>::ld(dst + pix * ldd + c);
+        ET<T>::st(dst + pix * ldd + c, v);
+    }
+}
+extern "C" int ydl_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, int64_t npix, int C, int accumulate, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(src && dst && lds_ >= C && ldd >= C, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (C % V != 0 || lds_ % V != 0 || ldd % V != 0 || !aligned16(src) || !aligned16(dst)) {
+        int grid = sgrid(npix * C);
+        if (dtype == YDL_F32) copy2d_scalar_kernel<float><<<grid, 256, 0, st>>>((const float*)src, lds_, (float*)dst, ldd, npix, C, accumulate);
+        else copy2d_scalar_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, lds_, (bf16_t*)dst, ldd, npix, C, accumulate);
+        YDL_LAUNCH_CHECK();
+        return 0;
+    }
+    int grid = sgrid(npix * (Cp / V));
+    if (dtype == YDL_F32) copy2d_kernel<float><<<grid, 256, 0, st>>>((const float*)src, lds_, (float*)dst, ldd, npix, Cp, accumulate);
+    else copy2d_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, lds_, (bf16_t*)dst, ldd, npix, Cp, accumulate);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// model edge: NCHW f32 <-> NHWC T through an LDS transpose tile (64 pixels x C channels)
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int ldd,
+                                                           int C, long long HW) {
+    // thread = one pixel: coalesced plane reads (lanes = consecutive pixels), one 16-byte NHWC store per chunk
+    constexpr int V = ET<T>::V;
+    const int n = blockIdx.y;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* s = src + (size_t)n * C * HW + p;
+    T* d = dst + ((size_t)n * HW + p) * ldd;
+    for (int c0 = 0; c0 < ldd; c0 += V) {
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = (c0 + e < C) ? s[(size_t)(c0 + e) * HW] : 0.f;
+        *(uint4*)(d + c0) = pack16<T>(v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, int lds_, float* __restrict__ dst,
+                                                           int C, long long HW, int accumulate) {
+    constexpr int V = ET<T>::V;
+    const int n = blockIdx.y;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const T* s = src + ((size_t)n * HW + p) * lds_;
+    float* d = dst + (size_t)n * C * HW + p;
+    for (int c0 = 0; c0 < C; c0 += V) {
+        float v[V];
+        unpack16<T>(*(const uint4*)(s + c0), v);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            if (c0 + e < C) {
+                float o = v[e];
+                if (accumulate) o += d[(size_t)(c0 + e) * HW];
+                d[(size_t)(c0 + e) * HW] = o;
+            }
+    }
+}
+extern "C" int ydl_nchw_to_nhwc(int dtype, const float* src, void* dst, int ldd, int N, int C, int H, int W, void* stream) {
+    YDL_CHECK(src && dst && ldd >= C && ldd % 8 == 0, "ldd must cover C and be a multiple of 8");
+    long long HW = (long long)H * W;
+    dim3 grid((unsigned)((HW + 255) / 256), N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(src, (float*)dst, ldd, C, HW);
+    else nchw_to_nhwc_kernel<bf16_t><<<grid, 256, 0, st>>>(src, (bf16_t*)dst, ldd, C, HW);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ydl_nhwc_to_nchw(int dtype, const void* src, int lds_, float* dst, int N, int C, int H, int W, int accumulate, void* stream) {
+    YDL_CHECK(src && dst && lds_ >= round_up(C, dtype == YDL_F32 ? 4 : 8), "source stride must cover C rounded to a chunk");
+    long long HW = (long long)H * W;
+    dim3 grid((unsigned)((HW + 255) / 256), N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) nhwc_to_nchw_kernel<float><<<grid, 256, 0, st>>>((const float*)src, lds_, dst, C, HW, accumulate);
+    else nhwc_to_nchw_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, lds_, dst, C, HW, accumulate);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// y[n,p,c] = x[n,p,c] * gate[n,c]
+template <typename T>
+__global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gate,
+                                                             T* __restrict__ y, int ldy, int N, long long hw, int C, int Cp) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = (long long)N * hw * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pix = i / cpp;
+        int c = (int)(i - pix * cpp) * V;
+        int n = (int)(pix / hw);
+        float v[V];
+        unpack16<T>(*(const uint4*)(x + pix * ldx + c), v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] *= (c + e < C) ? gate[(size_t)n * C + c + e] : 0.f;
+        *(uint4*)(y + pix * ldy + c) = pack16<T>(v);
+    }
+}
+extern "C" int ydl_scale_channels(int dtype, const void* x, int ldx, const float* gate, void* y, int ldy,
+                                  int N, int64_t hw, int C, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(x && y && gate && ldx >= Cp && ldy >= Cp, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = sgrid((long long)N * hw * (Cp / V));
+    if (dtype == YDL_F32) scale_channels_kernel<float><<<grid, 256, 0, st>>>((const float*)x, ldx, gate, (float*)y, ldy, N, hw, C, Cp);
+    else scale_channels_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, gate, (bf16_t*)y, ldy, N, hw, C, Cp);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

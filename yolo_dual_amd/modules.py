@@ -1,0 +1,496 @@
+"""nn.Module facade with the reference's names, constructor signatures and state_dict layout; all compute runs
+through yolo_dual_amd.tape on the HIP kernels.
+
+Both spellings of each block are served:
+  * seg-script blocks  — unet-lite/yolo5-seg/seg_diceloss_yolov5.py:388-507, yolov8/seg_jaccardloss_yolov8.py:401-414,
+    unet-lite/yolo9-seg/seg_diceloss_yolov9.py:451-510, segment/train.py:50-210
+  * stock YOLOv5 blocks — models/common.py:38-64 (Conv), :115-125 (Bottleneck), :161-172 (C3), :223-238 (SPPF),
+    :310-317 (Concat)
+Every module accepts either a tape ``Var`` (inside a model: one taped region for the whole network) or plain
+(N,C,H,W) f32 tensors (stand-alone use: the call becomes its own taped region behind one autograd node).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import config
+from .tape import Tape, Var, round_up, _p, _stream
+
+__all__ = ["autopad", "Conv", "C3", "C3Common", "Bottleneck", "C2f", "C3k2", "SPPF", "Concat", "Upsample",
+           "BasicBlock", "BottleneckBlock", "SegmentHead", "run_region"]
+
+
+def autopad(k, p=None, d=1):
+    """models/common.py:38-44 / seg_diceloss_yolov5.py:381-385."""
+    if d > 1:
+        k = d * (k - 1) + 1 if isinstance(k, int) else [d * (x - 1) + 1 for x in k]
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+# ----------------------------------------------------------------------------------------------------------
+# taped region behind ONE torch.autograd node
+# ----------------------------------------------------------------------------------------------------------
+class _Region(torch.autograd.Function):
+    """forward(fn, n_in, *tensors): tensors = n_in external inputs followed by the parameters the region may touch
+    (they are inputs only so that autograd schedules this node; their gradients are written into ``p.grad`` by the
+    kernels and ``None`` is returned for them)."""
+
+    @staticmethod
+    def forward(ctx, fn, n_in, *tensors):
+        ins = tensors[:n_in]
+        dev = ins[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("yolo_dual_amd runs on the GPU only: there is no CPU fallback for the HIP kernels "
+                               "(move the module and its inputs to cuda)")
+        record = any(ctx.needs_input_grad[2:])
+        tape = Tape(config.compute_dtype(), dev, fn.training, record)
+        vs = [tape.input_nchw(t) for t in ins]
+        for i, v in enumerate(vs):
+            v.need = bool(ctx.needs_input_grad[2 + i])
+        res = fn._fwd(tape, vs if fn.takes_list else vs[0]) if n_in else None
+        if isinstance(res, torch.Tensor):           # region already produced its external output (softmax head)
+            out_t, out_v = res, None
+        else:
+            out_v = res
+            out_t = tape.export_nchw(res)
+        ctx.tape, ctx.vs, ctx.out_v, ctx.fn = tape, vs, out_v, fn
+        ctx.n_extra = len(tensors) - n_in
+        return out_t
+
+    @staticmethod
+    def backward(ctx, gout):
+        tape: Tape = ctx.tape
+        if ctx.out_v is not None:
+            tape.seed_grad_nchw(ctx.out_v, gout)
+        else:
+            ctx.fn._seed_external(tape, gout)
+        tape.run_backward()
+        gins = [tape.grad_nchw(v) if v.need else None for v in ctx.vs]
+        ctx.tape = None
+        return (None, None, *gins, *([None] * ctx.n_extra))
+
+
+def run_region(fn: nn.Module, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
+    params = [p for p in fn.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+    return _Region.apply(fn, len(inputs), *inputs, *params)
+
+
+class YdlModule(nn.Module):
+    """base: dispatch between taped (Var) and stand-alone (torch.Tensor) calls"""
+    takes_list = False
+
+    def forward(self, x, *a, **kw):
+        if isinstance(x, Var):
+            return self._fwd(x.tape, x)
+        if isinstance(x, (list, tuple)) and x and isinstance(x[0], Var):
+            return self._fwd(x[0].tape, x)
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        return run_region(self, xs)
+
+    def _fwd(self, tape: Tape, x):
+        raise NotImplementedError
+
+    def _seed_external(self, tape: Tape, gout: torch.Tensor) -> None:
+        raise NotImplementedError
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Conv = Conv2d(bias=False) -> BatchNorm2d -> SiLU
+# ----------------------------------------------------------------------------------------------------------
+class _BNHolder(nn.BatchNorm2d):
+    """Parameter/buffer holder with nn.BatchNorm2d's state_dict layout.  ``num_batches_tracked`` is advanced on the
+    host and flushed into the buffer whenever the state is read, so the hot loop launches no extra kernel."""
+
+    def __init__(self, c):
+        super().__init__(c)
+        self._nbt_pending = 0
+        self.register_state_dict_pre_hook(_BNHolder._flush_hook)
+
+    @staticmethod
+    def _flush_hook(module, prefix, keep_vars):
+        module.flush()
+
+    def flush(self):
+        if self._nbt_pending:
+            self.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+
+    def forward(self, x):  # pragma: no cover - never used: BN is fused into the conv epilogue + apply kernels
+        raise RuntimeError("BatchNorm is fused into yolo_dual_amd.Conv; call the Conv module")
+
+
+def _act_code(act) -> int:
+    if act is True or isinstance(act, nn.SiLU):
+        return L.ACT_SILU
+    if act is False or act is None or isinstance(act, nn.Identity):
+        return L.ACT_NONE
+    if isinstance(act, nn.ReLU):
+        return L.ACT_RELU
+    raise NotImplementedError(f"activation {act!r} is not supported by the HIP path (SiLU/ReLU/Identity)")
+
+
+class Conv(YdlModule):
+    """``Conv(c1, c2, k=1, s=1, p=None, g=1, act=True)`` (seg scripts) and
+    ``Conv(c1, c2, k=1, s=1, p=None, g=1, d=1, act=True)`` (models/common.py): the 7th positional argument is taken
+    as ``act`` when it is a bool/Module and as the dilation when it is an int > 0 that is not a bool."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d_or_act=True, act=None):
+        super().__init__()
+        if act is None:
+            if isinstance(d_or_act, bool) or isinstance(d_or_act, nn.Module) or d_or_act is None:
+                act, d = d_or_act, 1
+            else:
+                d, act = int(d_or_act), True
+        else:
+            d = int(d_or_act) if not isinstance(d_or_act, bool) else 1
+        if not all(isinstance(v, int) and not isinstance(v, bool) for v in (c1, c2, k, s, g)):
+            raise TypeError(f"Conv arguments must be int: c1={c1}({type(c1)}), c2={c2}({type(c2)})")
+        if g <= 0 or c1 % g != 0:
+            raise ValueError(f"groups g={g} must be positive and divide c1={c1}")
+        if g != 1 or d != 1:
+            raise NotImplementedError("the HIP implicit-GEMM path implements groups=1, dilation=1")
+        self.c1, self.c2, self.k, self.s = c1, c2, k, s
+        self.p = autopad(k, p)
+        self.conv = nn.Conv2d(c1, c2, k, s, self.p, groups=g, bias=False)
+        self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+        self.bn = _BNHolder(c2)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+        self.act_code = _act_code(self.act)
+        self._wcache = {}
+
+    # -- parameters in compute layout -------------------------------------------------------------------
+    def _master_krsc(self) -> torch.Tensor:
+        w = self.conv.weight.detach().permute(0, 2, 3, 1)
+        if not w.is_contiguous():                      # someone re-assigned .data in OIHW order: re-home it
+            self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+            w = self.conv.weight.detach().permute(0, 2, 3, 1)
+            if not w.is_contiguous():
+                w = w.contiguous()
+        return w
+
+    def compute_weights(self, tape: Tape):
+        wp = self.conv.weight
+        key = (tape.dname, wp.data_ptr(), wp._version, config.weight_epoch())
+        hit = self._wcache.get("key")
+        if hit == key:
+            return self._wcache["w"], self._wcache["wt"]
+        master = self._master_krsc()
+        kk = self.k * self.k
+        cin_p, cout_p = round_up(self.c1, 8), round_up(self.c2, 8)
+        dev = master.device
+        w = self._wcache.get("w")
+        if w is None or self._wcache.get("dname") != tape.dname or w.device != dev:
+            w = torch.empty((self.c2, kk, cin_p), dtype=tape.tdt, device=dev)
+            wt = torch.empty((self.c1, kk, cout_p), dtype=tape.tdt, device=dev)
+        else:
+            wt = self._wcache["wt"]
+        L.call("ydl_weight_prep", tape.dt, _p(master), _p(w), _p(wt), self.c2, kk, self.c1, _stream())
+        self._wcache = {"key": key, "w": w, "wt": wt, "dname": tape.dname}
+        return w, wt
+
+    def coeffs(self, device):
+        cp = round_up(self.c2, 8)
+        buf = (torch.zeros if cp != self.c2 else torch.empty)((4, cp), dtype=torch.float32, device=device)
+        return {"mean": buf[0], "invstd": buf[1], "scale": buf[2], "shift": buf[3]}
+
+    def _grad_of(self, p: nn.Parameter) -> torch.Tensor:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)       # preserves the KRSC (channels_last) strides of the weight
+        return p.grad
+
+    def grad_slot(self, tape: Tape, which: str):
+        p = self.bn.weight if which == "gamma" else self.bn.bias
+        config.mark_touched(p)
+        return self._grad_of(p), 1
+
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
+        p = self.conv.weight
+        g = self._grad_of(p)
+        gk = g.permute(0, 2, 3, 1)
+        kk = self.k * self.k
+        cin_p = round_up(self.c1, 8)
+        if cin_p == self.c1 and gk.is_contiguous():
+            L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(gk), st)
+            config.mark_touched(p)
+            return
+        tmp = torch.zeros((self.c2, kk, cin_p), dtype=torch.float32, device=g.device)
+        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(tmp), st)
+        if gk.is_contiguous():
+            L.call("ydl_wgrad_unpad", _p(tmp), _p(gk), self.c2, kk, self.c1, 1, st)
+        else:                                           # exotic grad layout: let torch place it (cold path)
+            g.add_(tmp[:, :, :self.c1].view(self.c2, self.k, self.k, self.c1).permute(0, 3, 1, 2))
+        config.mark_touched(p)
+
+    # -- forward ----------------------------------------------------------------------------------------
+    def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None, res: Optional[Var] = None,
+             res_mode: int = L.RES_NONE, act_code: Optional[int] = None) -> Var:
+        if tape.train:
+            self.bn._nbt_pending += 1
+        return tape.conv_bn_act(x, self, self.s, self.p, self.act_code if act_code is None else act_code,
+                                out=out, res=res, res_mode=res_mode)
+
+    def forward_fuse(self, x):
+        raise NotImplementedError("inference-time Conv+BN folding is out of scope (SURVEY §8f-2)")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# CSP blocks
+# ----------------------------------------------------------------------------------------------------------
+class C3(YdlModule):
+    """Seg-script C3 (seg_diceloss_yolov5.py:416-428): cv3(cat(m(cv1 x), cv2 x)) (+ x), m = n plain 3x3 Convs."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Conv(c_, c_, 3, 1, g=g) for _ in range(n)))
+        self.add = shortcut and c1 == c2
+        self.c_ = c_
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        c_ = self.c_
+        cat = tape.new(x.N, 2 * c_, x.H, x.W)
+        left, right = cat.slice(0, c_), cat.slice(c_, 2 * c_)
+        n = len(self.m)
+        a = self.cv1._fwd(tape, x, out=left if n == 0 else None)
+        for i, mm in enumerate(self.m):
+            a = mm._fwd(tape, a, out=left if i == n - 1 else None)
+        self.cv2._fwd(tape, x, out=right)
+        if self.add:
+            return self.cv3._fwd(tape, cat, res=x, res_mode=L.RES_AFTER_ACT)
+        return self.cv3._fwd(tape, cat)
+
+
+class C3k2(C3):
+    """yolo9 C3k2 (seg_diceloss_yolov9.py:451-472) = script C3; its crop-align branch can never trigger because both
+    branches are stride-1 'same' convolutions of the same input."""
+
+
+class Bottleneck(YdlModule):
+    """models/common.py:115-125."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None) -> Var:
+        h = self.cv1._fwd(tape, x)
+        if self.add:
+            return self.cv2._fwd(tape, h, out=out, res=x, res_mode=L.RES_AFTER_ACT)
+        return self.cv2._fwd(tape, h, out=out)
+
+
+class C3Common(YdlModule):
+    """models/common.py:161-172: m = n Bottlenecks (e=1.0), no outer residual.  Exposed to parse_model as ``C3``."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
+        self.c_ = c_
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        c_ = self.c_
+        cat = tape.new(x.N, 2 * c_, x.H, x.W)
+        left, right = cat.slice(0, c_), cat.slice(c_, 2 * c_)
+        n = len(self.m)
+        a = self.cv1._fwd(tape, x, out=left if n == 0 else None)
+        for i, mm in enumerate(self.m):
+            a = mm._fwd(tape, a, out=left if i == n - 1 else None)
+        self.cv2._fwd(tape, x, out=right)
+        return self.cv3._fwd(tape, cat)
+
+
+class C2f(YdlModule):
+    """yolov8/seg_jaccardloss_yolov8.py:401-414.  cv1 writes the first two chunks of the concat buffer directly."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Conv(self.c, self.c, 3, 1, g=g) for _ in range(n))
+        self.add = shortcut and c1 == c2
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        c, n = self.c, len(self.m)
+        cat = tape.new(x.N, (2 + n) * c, x.H, x.W)
+        self.cv1._fwd(tape, x, out=cat.slice(0, 2 * c))
+        last = cat.slice(c, 2 * c)
+        for i, mm in enumerate(self.m):
+            last = mm._fwd(tape, last, out=cat.slice((2 + i) * c, (3 + i) * c))
+        if self.add:
+            return self.cv2._fwd(tape, cat, res=x, res_mode=L.RES_AFTER_ACT)
+        return self.cv2._fwd(tape, cat)
+
+
+class SPPF(YdlModule):
+    """seg_diceloss_yolov5.py:468-481 / models/common.py:223-238: three chained 5x5/s1 max-pools written straight into
+    the 4-way concat buffer."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.k = k
+        self.c_ = c_
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        c_ = self.c_
+        cat = tape.new(x.N, 4 * c_, x.H, x.W)
+        s0 = self.cv1._fwd(tape, x, out=cat.slice(0, c_))
+        s1 = tape.maxpool(s0, self.k, 1, self.k // 2, out=cat.slice(c_, 2 * c_))
+        s2 = tape.maxpool(s1, self.k, 1, self.k // 2, out=cat.slice(2 * c_, 3 * c_))
+        tape.maxpool(s2, self.k, 1, self.k // 2, out=cat.slice(3 * c_, 4 * c_))
+        return self.cv2._fwd(tape, cat)
+
+
+class Concat(YdlModule):
+    """Auto-aligning Concat (seg_diceloss_yolov5.py:484-507); with equal sizes it is models/common.py:310-317."""
+    takes_list = True
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+        if dimension != 1:
+            raise NotImplementedError("Concat along the channel dimension only")
+
+    def _fwd(self, tape: Tape, xs: Sequence[Var]) -> Var:
+        if len(xs) == 1:
+            return xs[0]
+        return tape.concat(xs, align=True)
+
+
+class Upsample(YdlModule):
+    """nn.Upsample restated for the taped path (nearest, or bilinear with either align_corners convention)."""
+
+    def __init__(self, size=None, scale_factor=None, mode="nearest", align_corners=None):
+        super().__init__()
+        self.size = size
+        self.scale_factor = scale_factor
+        self.mode = mode
+        self.align_corners = align_corners
+        if mode not in ("nearest", "bilinear"):
+            raise NotImplementedError(f"Upsample mode {mode}")
+
+    def _out_size(self, x: Var):
+        if self.size is not None:
+            return (self.size, self.size) if isinstance(self.size, int) else tuple(self.size)
+        sf = self.scale_factor
+        sh, sw = (sf, sf) if not isinstance(sf, (tuple, list)) else sf
+        return int(math.floor(x.H * sh)), int(math.floor(x.W * sw))
+
+    def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None) -> Var:
+        Ho, Wo = self._out_size(x)
+        if self.mode == "nearest":
+            # ATen passes 1/scale_factor as the index scale when a scale_factor was given
+            if self.size is None:
+                sf = self.scale_factor
+                sh, sw = (sf, sf) if not isinstance(sf, (tuple, list)) else sf
+                return tape.resize(x, Ho, Wo, L.RESIZE_NEAREST, 1.0 / sh, 1.0 / sw, out=out)
+            return tape.resize(x, Ho, Wo, L.RESIZE_NEAREST, out=out)
+        mode = L.RESIZE_BILINEAR_AC if self.align_corners else L.RESIZE_BILINEAR
+        if self.size is None and not self.align_corners:
+            sf = self.scale_factor
+            sh, sw = (sf, sf) if not isinstance(sf, (tuple, list)) else sf
+            return tape.resize(x, Ho, Wo, mode, 1.0 / sh, 1.0 / sw, out=out)
+        return tape.resize(x, Ho, Wo, mode, out=out)
+
+    def extra_repr(self):
+        return f"size={self.size}, scale_factor={self.scale_factor}, mode={self.mode}"
+
+
+# ----------------------------------------------------------------------------------------------------------
+# ResNet blocks + multi-scale SegmentHead (segment/train.py:74-210, Resnet18/seg_diceloss_resnet18.py:216-349)
+# ----------------------------------------------------------------------------------------------------------
+class BasicBlock(YdlModule):
+    expansion = 1
+
+    def __init__(self, in_channels, out_channels, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv(in_channels, out_channels, 3, stride, 1, act=True)
+        self.conv2 = Conv(out_channels, out_channels, 3, 1, 1, act=False)
+        self.downsample = downsample
+        self.act = nn.ReLU(inplace=True)
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        out = self.conv1._fwd(tape, x)
+        idt = x if self.downsample is None else self.downsample._fwd(tape, x)
+        # relu(bn(conv2(out)) + identity) fused into conv2's apply kernel
+        return self.conv2._fwd(tape, out, res=idt, res_mode=L.RES_BEFORE_ACT, act_code=L.ACT_RELU)
+
+
+class BottleneckBlock(YdlModule):
+    expansion = 4
+
+    def __init__(self, in_channels, mid_channels, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv(in_channels, mid_channels, 1, 1, 0, act=True)
+        self.conv2 = Conv(mid_channels, mid_channels, 3, stride, 1, act=True)
+        self.conv3 = Conv(mid_channels, mid_channels * self.expansion, 1, 1, 0, act=False)
+        self.downsample = downsample
+        self.act = nn.ReLU(inplace=True)
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        out = self.conv2._fwd(tape, self.conv1._fwd(tape, x))
+        idt = x if self.downsample is None else self.downsample._fwd(tape, x)
+        return self.conv3._fwd(tape, out, res=idt, res_mode=L.RES_BEFORE_ACT, act_code=L.ACT_RELU)
+
+
+class MaxPool2d(YdlModule):
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super().__init__()
+        self.k, self.s, self.p = kernel_size, stride or kernel_size, padding
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        return tape.maxpool(x, self.k, self.s, self.p)
+
+
+class SegmentHead(YdlModule):
+    """segment/train.py:159-210: lateral 1x1 -> 128, bilinear(align_corners=True) x2^i, cat, 3x3 -> 256, 1x1 -> nc."""
+    takes_list = True
+
+    def __init__(self, num_classes: int = 12, in_channels: List[int] = [256, 512, 1024]):
+        super().__init__()
+        self.num_classes = num_classes
+        self.lateral_convs = nn.ModuleList()
+        self.up_samples = nn.ModuleList()
+        for i, c in enumerate(in_channels):
+            self.lateral_convs.append(Conv(c, 128, 1, 1))
+            self.up_samples.append(Upsample(scale_factor=2 ** i, mode="bilinear", align_corners=True))
+        self.final_conv = nn.Sequential(Conv(128 * len(in_channels), 256, 3, 1), Conv(256, num_classes, 1, 1, act=False))
+
+    def _fwd(self, tape: Tape, feats: Sequence[Var]) -> Var:
+        if len(feats) != len(self.lateral_convs):
+            raise ValueError(f"feature count mismatch: expected {len(self.lateral_convs)}, got {len(feats)}")
+        H, W = feats[0].H, feats[0].W
+        cat = tape.new(feats[0].N, 128 * len(feats), H, W)
+        for i, (f, lat, up) in enumerate(zip(feats, self.lateral_convs, self.up_samples)):
+            sl = cat.slice(128 * i, 128 * (i + 1))
+            if (f.H, f.W) == (H, W):
+                lat._fwd(tape, f, out=sl)
+                continue
+            f = lat._fwd(tape, f)
+            Ho, Wo = up._out_size(f)
+            if (Ho, Wo) == (H, W):
+                up._fwd(tape, f, out=sl)
+            else:                                   # F.interpolate(size=target, align_corners=True) fallback
+                f = up._fwd(tape, f)
+                tape.resize(f, H, W, L.RESIZE_BILINEAR_AC, out=sl)
+        return self.final_conv[1]._fwd(tape, self.final_conv[0]._fwd(tape, cat))

@@ -1,0 +1,201 @@
+"""Flat-arena SGD(nesterov) + EMA: the optimizer step of the hot path as ONE fused HIP kernel per parameter run.
+
+Semantics restate ``smart_optimizer(model, 'SGD', lr, momentum, decay)`` (utils/torch_utils.py:318-346: three groups —
+biases / BN weights without decay, other weights with decay; torch.optim.SGD(nesterov=True)) and ``ModelEMA``
+(utils/torch_utils.py:404-428: every float entry of the state_dict, decay ``d = 0.9999 (1 - exp(-n/2000))``).
+
+MI355X-first layout: parameters, gradients, momentum and the EMA shadow each live in one contiguous f32 arena
+``[weights with decay | BN weights | biases | float buffers]``.  ``p.data`` / ``p.grad`` of every parameter are views
+of the arenas (conv weights keep their KRSC physical layout), so
+  * the wgrad / BN-backward kernels write gradients straight into the arena,
+  * ``zero_grad`` is one memset, the step is one streaming kernel per run, and
+  * data-parallel all-reduce works on a few large contiguous ranges (yolo_dual_amd.parallel).
+Parameters whose gradient was not produced in the current step (the reference's dead head layers) are
+skipped exactly like torch.optim.SGD skips ``grad is None``: no weight decay, no momentum update."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import config
+from .tape import _p, _stream
+
+
+def _is_bn(m: nn.Module) -> bool:
+    return "Norm" in type(m).__name__ or isinstance(m, nn.modules.batchnorm._BatchNorm)
+
+
+class FlatSGDEMA(torch.optim.Optimizer):
+    def __init__(self, model: nn.Module, lr: float = 0.01, momentum: float = 0.937, weight_decay: float = 5e-4,
+                 ema: bool = True, ema_decay: float = 0.9999, ema_tau: float = 2000.0, ema_updates: int = 0):
+        g0, g1, g2 = [], [], []          # decay weights, BN weights, biases   (names kept for the arena order)
+        seen = set()
+        for mod in model.modules():
+            for pname, p in mod.named_parameters(recurse=False):
+                if id(p) in seen:
+                    continue
+                seen.add(id(p))
+                if pname == "bias":
+                    g2.append(p)
+                elif pname == "weight" and _is_bn(mod):
+                    g1.append(p)
+                else:
+                    g0.append(p)
+        bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
+        self.model = model
+        self._groups3 = (g0, g1, g2)
+        self._bufs = bufs
+        dev = next(model.parameters()).device
+        sizes = [sum(p.numel() for p in g) for g in (g0, g1, g2)]
+        self.n_params = sum(sizes)
+        self.n_total = self.n_params + sum(b.numel() for b in bufs)
+        self.params_arena = torch.empty(self.n_total, dtype=torch.float32, device=dev)
+        self.grads_arena = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.mom_arena = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.ema_arena = torch.empty(self.n_total, dtype=torch.float32, device=dev) if ema else None
+        self._slots: List[Tuple[nn.Parameter, int, int, int]] = []      # (param, offset, numel, group)
+        off = 0
+        for gi, g in enumerate((g0, g1, g2)):
+            for p in g:
+                n = p.numel()
+                self._rehome(p, off, n)
+                self._slots.append((p, off, n, gi))
+                off += n
+        self._buf_slots = []
+        for b in bufs:
+            n = b.numel()
+            view = self.params_arena[off:off + n].view(b.shape)
+            view.copy_(b.data)
+            b.data = view
+            self._buf_slots.append((b, off, n))
+            off += n
+        if ema:
+            self.ema_arena.copy_(self.params_arena)
+        self.ema_decay, self.ema_tau, self.updates = ema_decay, ema_tau, ema_updates
+        self._has_buf: Dict[int, bool] = {}
+        # torch.optim.Optimizer plumbing (lr schedulers read/write param_groups[*]['lr']); group order follows
+        # smart_optimizer: biases, decay weights, BN weights
+        defaults = dict(lr=lr, momentum=momentum, nesterov=True, weight_decay=0.0)
+        super().__init__([{"params": g2 or [torch.nn.Parameter(torch.zeros(0, device=dev))]},
+                          {"params": g0, "weight_decay": weight_decay},
+                          {"params": g1, "weight_decay": 0.0}], defaults)
+        config.bump_weight_epoch()
+
+    # ------------------------------------------------------------------
+    def _rehome(self, p: nn.Parameter, off: int, n: int) -> None:
+        flat = self.params_arena[off:off + n]
+        gflat = self.grads_arena[off:off + n]
+        if p.dim() == 4:
+            O, I, kh, kw = p.shape
+            view = flat.view(O, kh, kw, I).permute(0, 3, 1, 2)          # KRSC physical, OIHW logical
+            gview = gflat.view(O, kh, kw, I).permute(0, 3, 1, 2)
+        else:
+            view, gview = flat.view(p.shape), gflat.view(p.shape)
+        view.copy_(p.data)
+        p.data = view
+        p.grad = gview
+        p._ydl_touched = False
+
+    def reattach(self) -> None:
+        """(re)bind ``p.grad`` to the arena (needed if foreign code set grads to None)"""
+        for p, off, n, _g in self._slots:
+            if p.grad is None or p.grad.data_ptr() != self.grads_arena.data_ptr() + 4 * off:
+                gflat = self.grads_arena[off:off + n]
+                p.grad = gflat.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2) if p.dim() == 4 \
+                    else gflat.view(p.shape)
+
+    def zero_grad(self, set_to_none: bool = False) -> None:   # grads stay attached to the arena
+        self.grads_arena.zero_()
+        self.reattach()
+        for p, *_ in self._slots:
+            p._ydl_touched = False
+
+    def live_ranges(self) -> List[Tuple[int, int]]:
+        """contiguous arena ranges [a, b) of parameters that received a gradient this step"""
+        out: List[Tuple[int, int]] = []
+        for p, off, n, _g in self._slots:
+            if getattr(p, "_ydl_touched", False):
+                if out and out[-1][1] == off:
+                    out[-1] = (out[-1][0], off + n)
+                else:
+                    out.append((off, off + n))
+        return out
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        lr_bias, lr_w, lr_bn = (g["lr"] for g in self.param_groups)
+        mom = self.param_groups[1]["momentum"]
+        wd = self.param_groups[1]["weight_decay"]
+        lrs = (lr_w, lr_bn, lr_bias)
+        d = -1.0
+        if self.ema_arena is not None:
+            self.updates += 1
+            d = self.ema_decay * (1.0 - math.exp(-self.updates / self.ema_tau))
+        st = _stream()
+        # maximal runs of consecutive slots with identical (touched, group, first-step) state
+        runs: List[List] = []
+        for p, off, n, gi in self._slots:
+            touched = bool(getattr(p, "_ydl_touched", False))
+            first = touched and not self._has_buf.get(id(p), False)
+            key = (touched, gi, first)
+            if runs and runs[-1][0] == key and runs[-1][2] == off:
+                runs[-1][2] = off + n
+            else:
+                runs.append([key, off, off + n])
+            if touched:
+                self._has_buf[id(p)] = True
+        pa, ga, ma = self.params_arena, self.grads_arena, self.mom_arena
+        ea = self.ema_arena
+        for (touched, gi, first), a, b in runs:
+            n = b - a
+            eptr = _p(ea[a:b]) if ea is not None else None
+            if touched:
+                nd = n if gi == 0 else 0
+                L.call("ydl_sgd_ema_step", _p(pa[a:b]), _p(ga[a:b]), _p(ma[a:b]), eptr, nd, n, n,
+                       lrs[gi], lrs[gi], mom, wd if gi == 0 else 0.0, grad_scale, 1 if first else 0, d, st)
+            elif ea is not None:
+                L.call("ydl_sgd_ema_step", _p(pa[a:b]), _p(ga[a:b]), _p(ma[a:b]), eptr, 0, 0, n,
+                       0.0, 0.0, mom, 0.0, 1.0, 0, d, st)
+        if ea is not None and self.n_total > self.n_params:
+            a, b = self.n_params, self.n_total
+            L.call("ydl_sgd_ema_step", _p(pa[a:b]), _p(ga), _p(ma), _p(ea[a:b]), 0, 0, b - a,
+                   0.0, 0.0, mom, 0.0, 1.0, 0, d, st)
+        config.bump_weight_epoch()
+        return None
+
+    # ------------------------------------------------------------------ EMA access (ModelEMA.ema equivalent)
+    def ema_state_dict(self) -> Dict[str, torch.Tensor]:
+        """state_dict of the EMA shadow (same keys as model.state_dict(); integer buffers are copied as is)."""
+        if self.ema_arena is None:
+            raise RuntimeError("EMA disabled")
+        by_ptr = {}
+        for p, off, n, _g in self._slots:
+            by_ptr[p.data_ptr()] = (off, n)
+        for b, off, n in self._buf_slots:
+            by_ptr[b.data_ptr()] = (off, n)
+        out = {}
+        for k, v in self.model.state_dict().items():
+            slot = by_ptr.get(v.data_ptr())
+            if slot is None or not v.dtype.is_floating_point:
+                out[k] = v.clone()
+                continue
+            off, n = slot
+            flat = self.ema_arena[off:off + n]
+            if v.dim() == 4:
+                O, I, kh, kw = v.shape
+                out[k] = flat.view(O, kh, kw, I).permute(0, 3, 1, 2).clone()
+            else:
+                out[k] = flat.view(v.shape).clone()
+        return out
+
+
+def smart_optimizer(model: nn.Module, name: str = "SGD", lr: float = 0.001, momentum: float = 0.9,
+                    decay: float = 1e-5, ema: bool = True) -> FlatSGDEMA:
+    """utils/torch_utils.py:318-346 signature; only the SGD-nesterov branch (what the seg scripts use) has a HIP path."""
+    if name != "SGD":
+        raise NotImplementedError(f"optimizer {name}: the fused HIP step implements the scripts' SGD(nesterov) only")
+    return FlatSGDEMA(model, lr=lr, momentum=momentum, weight_decay=decay, ema=ema)

@@ -1,0 +1,144 @@
+"""Batch-dimension data parallelism: one process per GPU, RCCL sum-all-reduce of the flat gradient arena over xGMI,
+overlapped with backward.
+
+The reference never creates a process group for segmentation (only nn.DataParallel; BN statistics stay
+per-GPU) — this is the new capability modelled on utils/torch_utils.py:55-63.  Design for the 8-GPU xGMI mesh:
+  * gradients already live in ONE contiguous f32 arena (yolo_dual_amd.optim.FlatSGDEMA), laid out in module order, so
+    backward completes it from the tail to the head;
+  * the arena is cut into a few large buckets (default 16 MiB: with 7 point-to-point links per GPU a ring step moves
+    1/8 of the bucket per link, so buckets must be MBs to reach link bandwidth) and a bucket's all-reduce is launched
+    on RCCL's stream as soon as the last gradient inside it has been enqueued (hook from the wgrad / BN-backward
+    launches), while earlier layers are still computing;
+  * parameters that get no gradient (dead head layers, ResNet layer4) are known after the first step and are
+    excluded: a bucket never waits for them, and their (zero) ranges are not sent;
+  * averaging (1/world) is folded into the optimizer kernel's ``grad_scale``.
+BatchNorm stays per-GPU exactly like the reference's DataParallel (its SyncBN branch is dead code)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import config
+from .optim import FlatSGDEMA
+
+
+class GradBucketReducer:
+    def __init__(self, opt: FlatSGDEMA, bucket_bytes: int = 16 << 20, group=None):
+        self.opt = opt
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(bucket_bytes // 4, 1)
+        self._plan: Optional[List[dict]] = None
+        self._slot_of: Dict[int, int] = {id(p): i for i, (p, *_r) in enumerate(opt._slots)}
+        self._handles: List = []
+        self._pending: Dict[int, int] = {}
+        self._live: Optional[List[bool]] = None
+        self._launched: List[Tuple[int, int]] = []
+        config.add_grad_hook(self._on_grad)
+
+    def close(self) -> None:
+        config.remove_grad_hook(self._on_grad)
+
+    # ------------------------------------------------------------------ planning
+    def _build_plan(self, live: List[bool]) -> None:
+        """buckets = contiguous arena ranges covering only live parameters, filled from the arena tail (the order in
+        which backward completes them)"""
+        slots = self.opt._slots
+        buckets: List[dict] = []
+        cur: Optional[dict] = None
+        for i in range(len(slots) - 1, -1, -1):
+            if not live[i]:
+                cur = None
+                continue
+            _p_, off, n, _g = slots[i]
+            if cur is not None and cur["a"] == off + n and (cur["b"] - off) <= self.bucket_elems:
+                cur["a"] = off
+                cur["slots"].append(i)
+            else:
+                cur = {"a": off, "b": off + n, "slots": [i]}
+                buckets.append(cur)
+        self._plan = buckets
+        self._bucket_of = {}
+        for bi, b in enumerate(buckets):
+            for si in b["slots"]:
+                self._bucket_of[si] = bi
+        self._live = list(live)
+
+    def begin_step(self) -> None:
+        self._handles = []
+        self._launched = []
+        if self._plan is not None:
+            self._pending = {bi: len(b["slots"]) for bi, b in enumerate(self._plan)}
+
+    # ------------------------------------------------------------------ hooks
+    def _on_grad(self, p) -> None:
+        if self.world == 1 or self._plan is None:
+            return
+        si = self._slot_of.get(id(p))
+        if si is None:
+            return
+        bi = self._bucket_of.get(si)
+        if bi is None:
+            return
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi: int) -> None:
+        b = self._plan[bi]
+        view = self.opt.grads_arena[b["a"]:b["b"]]
+        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched.append((b["a"], b["b"]))
+
+    # ------------------------------------------------------------------ end of backward
+    def finish(self) -> float:
+        """Wait for the in-flight buckets and return the grad_scale (1/world) for ``FlatSGDEMA.step``.
+        First step (or whenever the set of live parameters changes): ranges not yet reduced are reduced now and
+        the bucket plan is rebuilt for the following steps."""
+        if self.world == 1:
+            return 1.0
+        slots = self.opt._slots
+        live = [bool(getattr(p, "_ydl_touched", False)) for p, *_r in slots]
+        if self._plan is None or live != self._live:
+            covered = sorted(self._launched)
+            def is_covered(a, b):
+                return any(ca <= a and b <= cb for ca, cb in covered)
+            # coalesce the uncovered live slots into ranges and reduce them synchronously-launched
+            todo = []
+            for (p_, off, n, _g), lv in zip(slots, live):
+                if lv and not is_covered(off, off + n):
+                    if todo and todo[-1][1] == off:
+                        todo[-1][1] = off + n
+                    else:
+                        todo.append([off, off + n])
+            for a, b in todo:
+                self._handles.append(dist.all_reduce(self.opt.grads_arena[a:b], op=dist.ReduceOp.SUM,
+                                                     group=self.group, async_op=True))
+            self._build_plan(live)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._launched = []
+        return 1.0 / self.world
+
+
+class DataParallel:
+    """Thin training-step helper: ``dp = DataParallel(model, opt)``; per step ``dp.begin(); loss.backward();
+    scale = dp.finish(); opt.step(grad_scale=scale)``."""
+
+    def __init__(self, model, opt: FlatSGDEMA, bucket_bytes: int = 16 << 20, group=None, broadcast: bool = True):
+        self.model, self.opt = model, opt
+        self.reducer = GradBucketReducer(opt, bucket_bytes, group)
+        if broadcast and dist.is_initialized() and self.reducer.world > 1:
+            dist.broadcast(opt.params_arena, src=0, group=group)     # identical replicas (params + BN buffers)
+            if opt.ema_arena is not None:
+                opt.ema_arena.copy_(opt.params_arena)
+            config.bump_weight_epoch()
+
+    def begin(self) -> None:
+        self.reducer.begin_step()
+
+    def finish(self) -> float:
+        return self.reducer.finish()

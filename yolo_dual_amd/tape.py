@@ -1,0 +1,362 @@
+"""The MI355X-native runtime under the nn.Module facade: a static reverse-mode *tape* over NHWC device buffers.
+
+One forward pass of a model (or of a single block used on its own) records a list of backward closures; every
+primitive launches hand-written HIP kernels through the C ABI (include/ydl.h) on torch's current stream.  torch is
+plumbing only (allocator, streams, the autograd edge at the region boundary): there is no ATen compute inside a
+taped region.  Gradient fan-in is resolved by accumulate flags on the kernels (first writer overwrites, later
+writers add), concatenation is free (producers write channel slices of one buffer), and branches that never
+receive a gradient are skipped, which reproduces autograd's "grad is None" for the reference's dead head layers
+(SURVEY T4).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+_DT = {"f32": (L.YDL_F32, torch.float32), "bf16": (L.YDL_BF16, torch.bfloat16)}
+
+
+def round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Var:
+    """A NHWC activation: ``t`` is a logical (N,C,H,W) torch view whose memory is [N][H][W][ld] with c fastest."""
+    __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt")
+
+    def __init__(self, tape: "Tape", t: torch.Tensor, ld: int, need: bool, parent: Optional["Var"] = None, c0: int = 0):
+        self.tape = tape
+        self.dt = L.YDL_F32 if t.dtype == torch.float32 else L.YDL_BF16
+        self.t = t
+        self.N, self.C, self.H, self.W = t.shape
+        self.ld = ld
+        self.g: Optional[torch.Tensor] = None
+        self.gset = False
+        self.need = need
+        self.parent = parent
+        self.c0 = c0
+        self.children: List["Var"] = []
+
+    @property
+    def npix(self) -> int:
+        return self.N * self.H * self.W
+
+    def is_set(self) -> bool:
+        return self.gset or (self.parent is not None and self.parent.is_set())
+
+    def aligned(self) -> bool:
+        """16-byte channel alignment of a slice (whole buffers always are): required by the vector kernels"""
+        return self.parent is None or (self.c0 % 8 == 0 and self.C % 8 == 0 and self.parent.aligned())
+
+    def slice(self, c0: int, c1: int) -> "Var":
+        v = Var(self.tape, self.t[:, c0:c1], self.ld, self.need, parent=self, c0=c0)
+        self.children.append(v)
+        return v
+
+
+def _alloc(N: int, C: int, H: int, W: int, tdtype: torch.dtype, device, zero: bool = False) -> (torch.Tensor, int):
+    ld = round_up(C, 8)
+    mk = torch.zeros if (zero or ld != C) else torch.empty
+    buf = mk((N, H, W, ld), dtype=tdtype, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :C], ld
+
+
+class Tape:
+    def __init__(self, dtype: str, device, train: bool, record: bool):
+        self.dname = dtype
+        self.dt, self.tdt = _DT[dtype]
+        self.V = 4 if dtype == "f32" else 8
+        self.device = device
+        self.train = train
+        self.record = record
+        self.bw: List[Callable[[], None]] = []
+        self.touched_params: List[torch.nn.Parameter] = []
+        self.ext = None      # (Var, tensor) of a region whose external output was written directly (softmax head)
+
+    # ------------------------------------------------------------------ buffers
+    def new(self, N: int, C: int, H: int, W: int, need: bool = True, zero: bool = False, f32: bool = False) -> Var:
+        t, ld = _alloc(N, C, H, W, torch.float32 if f32 else self.tdt, self.device, zero)
+        return Var(self, t, ld, need)
+
+    def new_like(self, v: Var) -> Var:
+        return self.new(v.N, v.C, v.H, v.W, v.need, f32=(v.dt == L.YDL_F32))
+
+    def _gbuf(self, v: Var) -> torch.Tensor:
+        """gradient buffer of v (a slice shares its parent's buffer)"""
+        if v.g is None:
+            if v.parent is not None:
+                pg = self._gbuf(v.parent)
+                v.g = pg[:, v.c0:v.c0 + v.C]
+            else:
+                v.g, _ = _alloc(v.N, v.C, v.H, v.W, v.t.dtype, self.device)
+        return v.g
+
+    def grad_target(self, v: Var) -> (torch.Tensor, int):
+        """(buffer, accumulate) for a kernel about to write d/dv; marks v as set."""
+        g = self._gbuf(v)
+        acc = 1 if v.is_set() else 0
+        if not acc and v.children and any(c.gset for c in v.children):
+            # a slice already holds a gradient but the whole buffer does not: zero the rest, then accumulate
+            for c in v.children:
+                if not c.gset:
+                    self._gbuf(c).zero_()
+            covered = sorted((c.c0, c.c0 + c.C) for c in v.children)
+            pos = 0
+            for a, b in covered:
+                if a > pos:
+                    g[:, pos:a].zero_()
+                pos = max(pos, b)
+            if pos < v.C:
+                g[:, pos:].zero_()
+            acc = 1
+        v.gset = True
+        return g, acc
+
+    # ------------------------------------------------------------------ region boundary
+    def input_nchw(self, x: torch.Tensor) -> Var:
+        """external (N,C,H,W) f32 tensor (any strides) -> internal NHWC compute dtype, channels zero padded"""
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.contiguous().float()
+        N, C, H, W = x.shape
+        v = self.new(N, C, H, W, need=False, zero=True)
+        L.call("ydl_nchw_to_nhwc", self.dt, _p(x), _p(v.t), v.ld, N, C, H, W, _stream())
+        return v
+
+    def export_nchw(self, v: Var) -> torch.Tensor:
+        out = torch.empty((v.N, v.C, v.H, v.W), dtype=torch.float32, device=self.device)
+        L.call("ydl_nhwc_to_nchw", v.dt, _p(v.t), v.ld, _p(out), v.N, v.C, v.H, v.W, 0, _stream())
+        return out
+
+    def seed_grad_nchw(self, v: Var, g: torch.Tensor) -> None:
+        g = g.detach()
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.contiguous().float()
+        buf, acc = self.grad_target(v)
+        assert acc == 0
+        L.call("ydl_nchw_to_nhwc", v.dt, _p(g), _p(buf), v.ld, v.N, v.C, v.H, v.W, _stream())
+
+    def grad_nchw(self, v: Var) -> Optional[torch.Tensor]:
+        if not v.is_set():
+            return None
+        out = torch.empty((v.N, v.C, v.H, v.W), dtype=torch.float32, device=self.device)
+        L.call("ydl_nhwc_to_nchw", v.dt, _p(self._gbuf(v)), v.ld, _p(out), v.N, v.C, v.H, v.W, 0, _stream())
+        return out
+
+    def run_backward(self) -> None:
+        for fn in reversed(self.bw):
+            fn()
+        self.bw.clear()
+
+    # ------------------------------------------------------------------ conv + BN + act (+ residual)
+    def conv_bn_act(self, x: Var, m, s: int, p: int, act: int, out: Optional[Var] = None,
+                    res: Optional[Var] = None, res_mode: int = L.RES_NONE) -> Var:
+        """out = act(bn(conv(x))) [+ res].  ``m`` is a yolo_dual_amd.modules.Conv (parameter holder).
+        Reference: Conv.forward seg_diceloss_yolov5.py:403-409."""
+        k = m.k
+        Cout, Cin = m.c2, m.c1
+        if x.C != Cin:
+            raise RuntimeError(f"Conv layer input channel mismatch: got {x.C}, weight expects {Cin}")
+        if not x.aligned():                       # odd channel split: stage through an aligned buffer (cold path)
+            x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need))
+        if res is not None and not res.aligned():
+            res = self.copy(res, self.new(res.N, res.C, res.H, res.W, need=res.need))
+        if out is not None and not out.aligned():
+            tmp = self.conv_bn_act(x, m, s, p, act, None, res, res_mode)
+            return self.copy(tmp, out)
+        Ho = (x.H + 2 * p - k) // s + 1
+        Wo = (x.W + 2 * p - k) // s + 1
+        y = self.new(x.N, Cout, Ho, Wo)
+        if out is None:
+            out = self.new(x.N, Cout, Ho, Wo)
+        elif (out.N, out.C, out.H, out.W) != (x.N, Cout, Ho, Wo):
+            raise RuntimeError("conv_bn_act: output slice has the wrong shape")
+        geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld)
+        gp = ctypes.byref(geom)
+        st = _stream()
+        w, wt = m.compute_weights(self)
+        Cp = round_up(Cout, 8)
+        cf = m.coeffs(self.device)                   # dict of f32 [Cp] tensors: mean, invstd, scale, shift
+        if self.train:
+            nbytes = L.lib().ydl_conv_fwd_stats_ws_bytes(gp, self.dt)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), _p(ws), st)
+            L.call("ydl_bn_finalize", _p(ws), L.lib().ydl_conv_fwd_grid_m(gp), L.lib().ydl_conv_fwd_block_m(gp),
+                   x.N * Ho * Wo, Cout, _p(m.bn.weight), _p(m.bn.bias), m.bn.eps, m.bn.momentum,
+                   _p(m.bn.running_mean), _p(m.bn.running_var), _p(cf["mean"]), _p(cf["invstd"]),
+                   _p(cf["scale"]), _p(cf["shift"]), st)
+        else:
+            L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), None, st)
+            L.call("ydl_bn_eval_coeffs", Cout, _p(m.bn.weight), _p(m.bn.bias), _p(m.bn.running_mean),
+                   _p(m.bn.running_var), m.bn.eps, _p(cf["scale"]), _p(cf["shift"]), st)
+        L.call("ydl_bn_act_fwd", self.dt, _p(y.t), y.ld, _p(cf["scale"]), _p(cf["shift"]),
+               _p(res.t) if res is not None else None, res.ld if res is not None else 0, res_mode, act,
+               _p(out.t), out.ld, x.N * Ho * Wo, Cp, st)
+        if not self.record:
+            return out
+        if not self.train:
+            raise RuntimeError("backward through eval-mode BatchNorm is not supported")
+
+        def bw():
+            if not out.is_set():
+                return                                   # dead branch: parameters keep grad None
+            dout = self._gbuf(out)
+            st2 = _stream()
+            dy = self.new(x.N, Cout, Ho, Wo)
+            dres_t, dres_ld, tmp_dres = None, 0, None
+            if res is not None and res.need and res_mode == L.RES_BEFORE_ACT:
+                if res.is_set():
+                    tmp_dres = self.new_like(res)
+                    dres_t, dres_ld = tmp_dres.t, tmp_dres.ld
+                else:
+                    gbuf, _ = self.grad_target(res)
+                    dres_t, dres_ld = gbuf, res.ld
+            nws = L.lib().ydl_bn_bwd_ws_bytes(out.npix, Cp) // 4
+            ws2 = torch.empty(nws, dtype=torch.float32, device=self.device)
+            gw, accw = m.grad_slot(self, "gamma")
+            gb, _ = m.grad_slot(self, "beta")
+            L.call("ydl_bn_act_bwd", self.dt, _p(y.t), y.ld, _p(dout), out.ld, _p(out.t), out.ld,
+                   _p(m.bn.weight), _p(cf["mean"]), _p(cf["invstd"]), _p(cf["scale"]), _p(cf["shift"]),
+                   res_mode, act, _p(dy.t), dy.ld, _p(dres_t), dres_ld, _p(gw), _p(gb), accw,
+                   _p(ws2), out.npix, Cout, Cp, st2)
+            if tmp_dres is not None:
+                gbuf, acc = self.grad_target(res)
+                L.call("ydl_copy2d", self.dt, _p(tmp_dres.t), tmp_dres.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
+            if res is not None and res.need and res_mode == L.RES_AFTER_ACT:
+                gbuf, acc = self.grad_target(res)
+                L.call("ydl_copy2d", self.dt, _p(dout), out.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
+            # weight gradient (f32, KRSC) accumulated into the parameter's grad storage
+            m.wgrad(self, gp, x, dy, st2)
+            if x.need:
+                gx, acc = self.grad_target(x)
+                L.call("ydl_conv_dgrad", gp, self.dt, _p(dy.t), _p(wt), _p(gx), acc, st2)
+            _keep = (geom,)   # keep the ctypes struct alive for the closure
+
+        self.bw.append(bw)
+        return out
+
+    # ------------------------------------------------------------------ pooling / resize / copies
+    def maxpool(self, x: Var, k: int, s: int, p: int, out: Optional[Var] = None) -> Var:
+        Ho = (x.H + 2 * p - k) // s + 1
+        Wo = (x.W + 2 * p - k) // s + 1
+        if not x.aligned():
+            x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need, f32=(x.dt == L.YDL_F32)))
+        if out is not None and not out.aligned():
+            return self.copy(self.maxpool(x, k, s, p), out)
+        if out is None:
+            out = self.new(x.N, x.C, Ho, Wo, f32=(x.dt == L.YDL_F32))
+        Cp = round_up(x.C, 4 if x.dt == L.YDL_F32 else 8)
+        idx = torch.empty((x.N * Ho * Wo * Cp,), dtype=torch.uint8, device=self.device) if self.record else None
+        L.call("ydl_maxpool_fwd", x.dt, _p(x.t), x.ld, _p(out.t), out.ld, _p(idx), x.N, x.H, x.W, Ho, Wo, x.C,
+               k, s, p, _stream())
+        if self.record:
+            def bw():
+                if not out.is_set() or not x.need:
+                    return
+                gx, acc = self.grad_target(x)
+                L.call("ydl_maxpool_bwd", x.dt, _p(self._gbuf(out)), out.ld, _p(idx), _p(gx), x.ld, acc,
+                       x.N, x.H, x.W, Ho, Wo, x.C, k, s, p, _stream())
+            self.bw.append(bw)
+        return out
+
+    def resize(self, x: Var, Ho: int, Wo: int, mode: int, scale_h: float = 0.0, scale_w: float = 0.0,
+               out: Optional[Var] = None) -> Var:
+        """mode: L.RESIZE_NEAREST / RESIZE_BILINEAR (align_corners=False) / RESIZE_BILINEAR_AC (True)."""
+        if not x.aligned():
+            x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need, f32=(x.dt == L.YDL_F32)))
+        if out is not None and not out.aligned():
+            return self.copy(self.resize(x, Ho, Wo, mode, scale_h, scale_w), out)
+        if out is None:
+            out = self.new(x.N, x.C, Ho, Wo, f32=(x.dt == L.YDL_F32))
+        L.call("ydl_resize_fwd", x.dt, mode, _p(x.t), x.ld, _p(out.t), out.ld, x.N, x.H, x.W, Ho, Wo, x.C,
+               scale_h, scale_w, _stream())
+        if self.record:
+            def bw():
+                if not out.is_set() or not x.need:
+                    return
+                gx, acc = self.grad_target(x)
+                L.call("ydl_resize_bwd", x.dt, mode, _p(self._gbuf(out)), out.ld, _p(gx), x.ld, acc,
+                       x.N, x.H, x.W, Ho, Wo, x.C, scale_h, scale_w, _stream())
+            self.bw.append(bw)
+        return out
+
+    def copy(self, x: Var, out: Var) -> Var:
+        """out[:] = x (channel-slice aware); backward adds d(out) into d(x)."""
+        L.call("ydl_copy2d", x.dt, _p(x.t), x.ld, _p(out.t), out.ld, x.npix, x.C, 0, _stream())
+        if self.record:
+            def bw():
+                if not out.is_set() or not x.need:
+                    return
+                gx, acc = self.grad_target(x)
+                L.call("ydl_copy2d", x.dt, _p(self._gbuf(out)), out.ld, _p(gx), x.ld, x.npix, x.C, acc, _stream())
+            self.bw.append(bw)
+        return out
+
+    def concat(self, xs: Sequence[Var], align: bool = True) -> Var:
+        """Concat along channels with the reference's auto-align (bilinear, align_corners=False, to the first
+        input's size) — seg_diceloss_yolov5.py:484-507.  Each source is written straight into its slice."""
+        H, W = xs[0].H, xs[0].W
+        Ct = sum(v.C for v in xs)
+        cat = self.new(xs[0].N, Ct, H, W, f32=(xs[0].dt == L.YDL_F32))
+        c0 = 0
+        for v in xs:
+            sl = cat.slice(c0, c0 + v.C)
+            if (v.H, v.W) == (H, W):
+                self.copy(v, sl)
+            elif align:
+                self.resize(v, H, W, L.RESIZE_BILINEAR, out=sl)
+            else:
+                raise RuntimeError("Concat: spatial sizes differ")
+            c0 += v.C
+        return cat
+
+    # ------------------------------------------------------------------ softmax head
+    def softmax(self, x: Var) -> Var:
+        """nn.Softmax(1) into an f32 NHWC Var (probabilities stay f32 even in bf16 mode)."""
+        out = self.new(x.N, x.C, x.H, x.W, zero=True, f32=True)
+        sn, sc, sh, sw = out.t.stride()
+        L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(out.t), sn, sc, sh, sw, x.N, x.H, x.W, x.C, _stream())
+        if self.record:
+            def bw():
+                if not out.is_set() or not x.need:
+                    return
+                dp = self._gbuf(out)
+                gx, acc = self.grad_target(x)
+                assert acc == 0, "softmax input must have a single consumer"
+                L.call("ydl_softmax_bwd", x.dt, _p(out.t), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, _stream())
+            self.bw.append(bw)
+        return out
+
+    def softmax_nchw(self, x: Var) -> torch.Tensor:
+        """nn.Softmax(1) producing the region's external output directly: f32 NCHW contiguous (no extra pass).
+        The region owner must call softmax_nchw_backward with the incoming gradient."""
+        p = torch.empty((x.N, x.C, x.H, x.W), dtype=torch.float32, device=self.device)
+        sn, sc, sh, sw = p.stride()
+        L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(p), sn, sc, sh, sw, x.N, x.H, x.W, x.C, _stream())
+        return p
+
+    def softmax_nchw_backward(self, x: Var, p: torch.Tensor, dp: torch.Tensor) -> None:
+        dp = dp.detach()
+        if dp.dtype != torch.float32 or dp.stride() != p.stride():
+            dp = dp.float().contiguous()
+        gx, acc = self.grad_target(x)
+        assert acc == 0
+        sn, sc, sh, sw = p.stride()
+        L.call("ydl_softmax_bwd", x.dt, _p(p), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, _stream())
+
+    def scale_channels(self, x: Var, gate: torch.Tensor) -> Var:
+        out = self.new_like(x)
+        L.call("ydl_scale_channels", x.dt, _p(x.t), x.ld, _p(gate), _p(out.t), out.ld, x.N, x.H * x.W, x.C, _stream())
+        return out
