@@ -1,0 +1,121 @@
+"""CPU, world_size 2, gloo: the data-parallel bucket reducer (yolo_dual_amd.parallel) — plan building from the set of
+live parameters, hook-triggered bucket launches in backward order, exclusion of dead parameters, liveness changes
+between steps, and the broadcast of the flat parameter arena.  Gradients are produced by writing into the arena and
+calling the same ``config.mark_touched`` hook the HIP wgrad / BN-backward launches call."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    import yolo_dual_amd as ydl
+    torch.manual_seed(0)
+    return nn.Sequential(ydl.Conv(8, 16, 3, 1), ydl.C3(16, 16, 1), ydl.Conv(16, 8, 1, 1), ydl.Conv(8, 8, 1, 1))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yolo_dual_amd import config
+        from yolo_dual_amd.optim import FlatSGDEMA
+        from yolo_dual_amd.parallel import DataParallel
+        net = _build()
+        if rank == 1:                      # replicas start different: the broadcast must equalise them
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(1.0)
+        opt = FlatSGDEMA(net, lr=0.1)
+        dp = DataParallel(net, opt, bucket_bytes=4096)      # tiny buckets -> several of them
+        ref0 = [torch.zeros_like(opt.params_arena) for _ in range(world)]
+        dist.all_gather(ref0, opt.params_arena)
+        assert torch.equal(ref0[0], ref0[1]), "broadcast did not equalise the replicas"
+
+        slots = opt._slots
+        dead = {id(p) for p in net[3].parameters()}           # last block never gets a gradient ("dead head layer")
+        expect_scale = 1.0 / world
+        for step in range(3):
+            opt.zero_grad()
+            dp.begin()
+            if step == 2:
+                dead = set()                                   # liveness changes: everything is live now
+            # backward order = reverse of module order; each rank writes rank-dependent gradients
+            for p, off, n, _g in reversed(slots):
+                if id(p) in dead:
+                    continue
+                opt.grads_arena[off:off + n] = (rank + 1) * (1.0 + 0.001 * torch.arange(n, dtype=torch.float32) + step)
+                config.mark_touched(p)
+            scale = dp.finish()
+            assert abs(scale - expect_scale) < 1e-12
+            for p, off, n, _g in slots:
+                got = opt.grads_arena[off:off + n]
+                if id(p) in dead:
+                    assert float(got.abs().max()) == 0.0       # dead ranges are neither written nor reduced
+                else:
+                    want = sum(r + 1 for r in range(world)) * (1.0 + 0.001 * torch.arange(n, dtype=torch.float32) + step)
+                    assert torch.allclose(got, want, rtol=1e-6), (step, off)
+            if step == 0:
+                plan = dp.reducer._plan
+                assert plan is not None and len(plan) >= 2
+                covered = sorted((b["a"], b["b"]) for b in plan)
+                live_elems = sum(n for p, off, n, _g in slots if id(p) not in dead)
+                assert sum(b - a for a, b in covered) == live_elems
+            if step == 1:
+                # second step: every bucket was launched from the hooks before finish()
+                assert all(v == 0 for v in dp.reducer._pending.values())
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_reducer_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_flat_arena_layout_and_state_dict_roundtrip():
+    """parameters become views of one arena; state_dict keys/shapes are untouched and load_state_dict writes through"""
+    from yolo_dual_amd.optim import FlatSGDEMA
+    net = _build()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = FlatSGDEMA(net, lr=0.1)
+    a0 = opt.params_arena.data_ptr()
+    for p, off, n, g in opt._slots:
+        assert p.data_ptr() == a0 + 4 * off and p.grad.data_ptr() == opt.grads_arena.data_ptr() + 4 * off
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    sd1 = {k: (v + 1 if v.dtype.is_floating_point else v) for k, v in sd0.items()}
+    net.load_state_dict(sd1)
+    w = net[0].conv.weight
+    assert torch.equal(w.detach(), sd1["0.conv.weight"])
+    # KRSC physical layout survives the load (copy_ preserves the destination strides)
+    assert w.permute(0, 2, 3, 1).is_contiguous()
+    flat = opt.params_arena[opt._slots[0][1]:opt._slots[0][1] + opt._slots[0][2]]
+    assert torch.equal(flat.view(16, 3, 3, 8), sd1["0.conv.weight"].permute(0, 2, 3, 1))
+    ema = opt.ema_state_dict()
+    assert set(ema) == set(sd0)

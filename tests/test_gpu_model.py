@@ -120,7 +120,7 @@ def test_bf16_tracks_f32():
     ydl.set_compute_dtype("bf16")
     assert l2_err(res["bf16"][0], res["f32"][0]) < 0.1
     assert abs(res["bf16"][1][0] - res["f32"][1][0]) <= 1e-2 * abs(res["f32"][1][0])
-    assert l2_err(res["bf16"][2], res["f32"][2]) < 0.25        # stem weight gradient: the longest bf16 chain
+    assert l2_err(res["bf16"][2], res["f32"][2]) < 0.4        # stem weight gradient: the longest bf16 chain
 
 
 def test_wgrad_transposed_read_matches_scalar_read():

@@ -137,40 +137,62 @@ extern "C" int ydl_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// apply: out = act(y*scale + shift) (+res).  One 16-byte chunk per thread iteration, grid-stride.
-// scale/shift arrays must be readable up to Cp (padded entries = 0 => padded channels stay 0 for SiLU/none).
+// Streaming kernels: a thread owns ONE 16-byte channel chunk for the whole kernel (its scale/shift/mean/invstd sit
+// in registers) and walks pixels with a 32-bit stride; a CTA covers R = 256/cpb pixels per iteration, where
+// cpb = min(chunks per pixel, 256).  No 64-bit divisions, no per-element coefficient loads.
 // ------------------------------------------------------------------------------------------------------
+struct Lay { int cpb, R, cq, pl; bool live; int c; };
+template <int V>
+__device__ __forceinline__ Lay make_lay(int Cp) {
+    Lay L;
+    const int cpp = Cp / V;
+    L.cpb = cpp < 256 ? cpp : 256;
+    L.R = 256 / L.cpb;
+    L.cq = threadIdx.x % L.cpb;
+    L.pl = threadIdx.x / L.cpb;
+    const int chunk = blockIdx.y * 256 + L.cq;
+    L.live = L.pl < L.R && chunk < cpp;
+    L.c = chunk * V;
+    return L;
+}
+static inline dim3 lay_grid(long long npix, int Cp, int V, int max_x) {
+    int cpp = Cp / V;
+    int cpb = cpp < 256 ? cpp : 256;
+    int R = 256 / cpb;
+    long long gx = (npix + R - 1) / R;
+    if (gx > max_x) gx = max_x;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)((cpp + 255) / 256));
+}
+
+// apply: out = act(y*scale + shift) (+res).
+// scale/shift arrays must be readable up to Cp (padded entries = 0 => padded channels stay 0 for SiLU/none).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int ldr,
                                                          int res_mode, int act, T* __restrict__ out, int ldo,
                                                          long long npix, int Cp) {
     constexpr int V = ET<T>::V;
-    const int cpp = Cp / V;
-    const long long total = npix * cpp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long pix = i / cpp;
-        int c = (int)(i - pix * cpp) * V;
+    const Lay L = make_lay<V>(Cp);
+    if (!L.live) return;
+    float sc[V], sf[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sc[e] = scale[L.c + e]; sf[e] = shift[L.c + e]; }
+    const long long stride = (long long)gridDim.x * L.R;
+    for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
         float v[V], r[V];
-        unpack16<T>(*(const uint4*)(y + pix * ldy + c), v);
-        if (res_mode != YDL_RES_NONE) unpack16<T>(*(const uint4*)(res + pix * ldr + c), r);
+        unpack16<T>(*(const uint4*)(y + pix * ldy + L.c), v);
+        if (res_mode != YDL_RES_NONE) unpack16<T>(*(const uint4*)(res + pix * ldr + L.c), r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            float z = v[e] * scale[c + e] + shift[c + e];
+            float z = v[e] * sc[e] + sf[e];
             if (res_mode == YDL_RES_BEFORE_ACT) z += r[e];
             float o = act == YDL_ACT_SILU ? silu_f(z) : (act == YDL_ACT_RELU ? fmaxf(z, 0.f) : z);
             if (res_mode == YDL_RES_AFTER_ACT) o += r[e];
             v[e] = o;
         }
-        *(uint4*)(out + pix * ldo + c) = pack16<T>(v);
+        *(uint4*)(out + pix * ldo + L.c) = pack16<T>(v);
     }
-}
-
-static inline int stream_grid(long long total_items) {
-    long long b = (total_items + 255) / 256;
-    if (b > 256 * 16) b = 256 * 16;
-    if (b < 1) b = 1;
-    return (int)b;
 }
 
 extern "C" int ydl_bn_act_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift,
@@ -182,7 +204,7 @@ extern "C" int ydl_bn_act_fwd(int dtype, const void* y, int ldy, const float* sc
     YDL_CHECK(res_mode == YDL_RES_NONE || (res != nullptr && ldr >= Cp), "residual requested but missing");
     YDL_CHECK(aligned16(y) && aligned16(out) && (res == nullptr || aligned16(res)), "16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
-    int grid = stream_grid(npix * (Cp / V));
+    dim3 grid = lay_grid(npix, Cp, V, 256 * 8);
     if (dtype == YDL_F32)
         bn_act_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)y, ldy, scale, shift, (const float*)res, ldr, res_mode, act, (float*)out, ldo, npix, Cp);
     else
@@ -194,22 +216,19 @@ extern "C" int ydl_bn_act_fwd(int dtype, const void* y, int ldy, const float* sc
 // ------------------------------------------------------------------------------------------------------
 // backward.  dz = dout * act'(z);  dbeta = sum dz;  dgamma = sum dz*xhat;
 //            dy = gamma*invstd * (dz - dbeta/M - xhat*dgamma/M)
-// phase 1: per-block partial (dbeta, dgamma) ; phase 2: tiny merge ; phase 3: streaming apply.
-// ws layout (floats): [nblk][2][Cp] partials, then [2][Cp] merged sums.
+// phase 1: per-CTA partial (dbeta, dgamma), fixed pixel->CTA assignment (deterministic) ; phase 2: merge in double ;
+// phase 3: streaming apply.   ws layout (floats): [nblk][2][Cp] partials, then [2][Cp] merged sums.
 // ------------------------------------------------------------------------------------------------------
-#define BWD_MAX_PARTIALS 256      // the merge kernel walks nblk/8 partials per thread: keep the chain short
-#define BWD_MIN_PIX_PER_BLOCK 256
+#define BWD_MAX_PARTIALS 1024
 
-static inline long long bwd_pix_per_block(long long npix) {
-    long long per = (npix + BWD_MAX_PARTIALS - 1) / BWD_MAX_PARTIALS;
-    if (per < BWD_MIN_PIX_PER_BLOCK) per = BWD_MIN_PIX_PER_BLOCK;
-    return per;
+static inline int bwd_nblk(long long npix, int Cp, int V) {
+    return (int)lay_grid(npix, Cp, V, BWD_MAX_PARTIALS).x;
 }
 
 template <typename T>
-__device__ __forceinline__ void load_dz(const T* y, const T* dout, const T* out, long long pix, int ldy, int lddo, int ldo,
-                                        int c, const float* scale, const float* shift, const float* mean,
-                                        const float* invstd, int act, float* dz, float* xh) {
+__device__ __forceinline__ void dz_xhat(const T* y, const T* dout, const T* out, long long pix, int ldy, int lddo, int ldo,
+                                        int c, const float* sc, const float* sf, const float* mu, const float* is,
+                                        int act, float* dz, float* xh) {
     constexpr int V = ET<T>::V;
     float yv[V], dv[V], ov[V];
     unpack16<T>(*(const uint4*)(y + pix * ldy + c), yv);
@@ -217,7 +236,7 @@ __device__ __forceinline__ void load_dz(const T* y, const T* dout, const T* out,
     if (act == YDL_ACT_RELU) unpack16<T>(*(const uint4*)(out + pix * ldo + c), ov);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-        float z = yv[e] * scale[c + e] + shift[c + e];
+        float z = yv[e] * sc[e] + sf[e];
         float d = dv[e];
         if (act == YDL_ACT_SILU) {
             float sg = sigmoid_f(z);
@@ -226,7 +245,7 @@ __device__ __forceinline__ void load_dz(const T* y, const T* dout, const T* out,
             d = ov[e] > 0.f ? d : 0.f;
         }
         dz[e] = d;
-        xh[e] = (yv[e] - mean[c + e]) * invstd[c + e];
+        xh[e] = (yv[e] - mu[e]) * is[e];
     }
 }
 
@@ -235,27 +254,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ out, int ldo,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            int act, float* __restrict__ part, long long npix, int Cp,
-                                                            long long pix_per_block) {
+                                                            int act, float* __restrict__ part, long long npix, int Cp) {
     constexpr int V = ET<T>::V;
-    const int cpp_all = Cp / V;                       // chunks per pixel
-    const int cgrp = min(cpp_all - blockIdx.y * 256, 256);   // chunks handled by this block column
-    const int cq = threadIdx.x % cgrp, pl = threadIdx.x / cgrp;
-    const int npl = 256 / cgrp;                       // pixel lanes
-    const int c = (blockIdx.y * 256 + cq) * V;
-    const long long p0 = (long long)blockIdx.x * pix_per_block;
-    const long long p1 = min(npix, p0 + pix_per_block);
-    float sb[V], sg[V];
+    const Lay L = make_lay<V>(Cp);
+    float sb[V], sg[V], sc[V], sf[V], mu[V], is[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { sb[e] = 0.f; sg[e] = 0.f; }
-    if (pl < npl)
-        for (long long pix = p0 + pl; pix < p1; pix += npl) {
+    if (L.live) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sc[e] = scale[L.c + e]; sf[e] = shift[L.c + e]; mu[e] = mean[L.c + e]; is[e] = invstd[L.c + e]; }
+        const long long stride = (long long)gridDim.x * L.R;
+        for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
             float dz[V], xh[V];
-            load_dz<T>(y, dout, out, pix, ldy, lddo, ldo, c, scale, shift, mean, invstd, act, dz, xh);
+            dz_xhat<T>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, act, dz, xh);
 #pragma unroll
             for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
         }
-    // reduce over pixel lanes through LDS
+    }
+    // reduce over the CTA's pixel lanes through LDS
     __shared__ float red[256 * 2 * 8];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -263,39 +279,48 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         red[(threadIdx.x * 2 + 1) * V + e] = sg[e];
     }
     __syncthreads();
-    if (threadIdx.x < cgrp) {
+    if (threadIdx.x < L.cpb && L.live) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float a = 0.f, b = 0.f;
-            for (int l = 0; l < npl; ++l) {
-                int tt = l * cgrp + threadIdx.x;
+            for (int l = 0; l < L.R; ++l) {
+                int tt = l * L.cpb + threadIdx.x;
                 a += red[(tt * 2 + 0) * V + e];
                 b += red[(tt * 2 + 1) * V + e];
             }
             float* dst = part + (size_t)blockIdx.x * 2 * Cp;
-            dst[c + e] = a;
-            dst[Cp + c + e] = b;
+            dst[L.c + e] = a;
+            dst[Cp + L.c + e] = b;
         }
     }
 }
 
+// 8 channels x 32 slices per CTA; four independent accumulators keep the partial loads in flight
 __global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restrict__ part, int nblk, int Cp, int C,
                                                            float* __restrict__ sums, float* dgamma, float* dbeta, int accumulate) {
-    __shared__ double sh[2][8][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < Cp)
-        for (int i = sl; i < nblk; i += 8) {
-            a += (double)part[(size_t)i * 2 * Cp + c];
-            b += (double)part[(size_t)i * 2 * Cp + Cp + c];
+    __shared__ double sh[2][32][9];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (c < Cp) {
+        int i = sl;
+        for (; i + 32 < nblk; i += 64) {
+            a0 += (double)part[(size_t)i * 2 * Cp + c];
+            b0 += (double)part[(size_t)i * 2 * Cp + Cp + c];
+            a1 += (double)part[(size_t)(i + 32) * 2 * Cp + c];
+            b1 += (double)part[(size_t)(i + 32) * 2 * Cp + Cp + c];
         }
-    sh[0][sl][cl] = a;
-    sh[1][sl][cl] = b;
+        if (i < nblk) {
+            a0 += (double)part[(size_t)i * 2 * Cp + c];
+            b0 += (double)part[(size_t)i * 2 * Cp + Cp + c];
+        }
+    }
+    sh[0][sl][cl] = a0 + a1;
+    sh[1][sl][cl] = b0 + b1;
     __syncthreads();
     if (sl == 0 && c < Cp) {
         double ta = 0.0, tb = 0.0;
-        for (int i = 0; i < 8; ++i) { ta += sh[0][i][cl]; tb += sh[1][i][cl]; }
+        for (int i = 0; i < 32; ++i) { ta += sh[0][i][cl]; tb += sh[1][i][cl]; }
         sums[c] = (float)ta;          // dbeta
         sums[Cp + c] = (float)tb;     // dgamma
         if (c < C) {
@@ -313,24 +338,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ sums, int act, T* __restrict__ dy, int lddy,
                                                            T* __restrict__ dres, int lddr, long long npix, int Cp) {
     constexpr int V = ET<T>::V;
-    const int cpp = Cp / V;
-    const long long total = npix * cpp;
+    const Lay L = make_lay<V>(Cp);
+    if (!L.live) return;
     const float invM = 1.0f / (float)npix;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long pix = i / cpp;
-        int c = (int)(i - pix * cpp) * V;
-        float dz[V], xh[V], o[V];
-        load_dz<T>(y, dout, out, pix, ldy, lddo, ldo, c, scale, shift, mean, invstd, act, dz, xh);
+    float sc[V], sf[V], mu[V], is[V], kb[V], kg[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = scale[c + e] * (dz[e] - (sums[c + e] + xh[e] * sums[Cp + c + e]) * invM);
-        *(uint4*)(dy + pix * lddy + c) = pack16<T>(o);
-        if (dres != nullptr) *(uint4*)(dres + pix * lddr + c) = pack16<T>(dz);
+    for (int e = 0; e < V; ++e) {
+        sc[e] = scale[L.c + e]; sf[e] = shift[L.c + e]; mu[e] = mean[L.c + e]; is[e] = invstd[L.c + e];
+        kb[e] = sums[L.c + e] * invM; kg[e] = sums[Cp + L.c + e] * invM;
+    }
+    const long long stride = (long long)gridDim.x * L.R;
+    for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
+        float dz[V], xh[V], o[V];
+        dz_xhat<T>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, act, dz, xh);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = sc[e] * (dz[e] - kb[e] - xh[e] * kg[e]);
+        *(uint4*)(dy + pix * lddy + L.c) = pack16<T>(o);
+        if (dres != nullptr) *(uint4*)(dres + pix * lddr + L.c) = pack16<T>(dz);
     }
 }
 
 extern "C" int64_t ydl_bn_bwd_ws_bytes(int64_t npix, int Cp) {
-    int64_t nblk = cdiv64(npix, bwd_pix_per_block(npix));
-    return (nblk * 2 * Cp + 2 * Cp) * (int64_t)sizeof(float);
+    (void)npix;
+    return ((int64_t)BWD_MAX_PARTIALS * 2 * Cp + 2 * Cp) * (int64_t)sizeof(float);
 }
 
 extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
@@ -345,19 +375,18 @@ extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dou
     YDL_CHECK(Cp > 0 && Cp % V == 0 && C <= Cp && ldy >= Cp && lddo >= Cp && lddy >= Cp, "bad channel geometry");
     YDL_CHECK(aligned16(y) && aligned16(dout) && aligned16(dy), "16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
-    const long long ppb = bwd_pix_per_block(npix);
-    int nblk = (int)cdiv64(npix, ppb);
+    dim3 g1 = lay_grid(npix, Cp, V, BWD_MAX_PARTIALS);
+    const int nblk = (int)g1.x;
     float* part = ws;
-    float* sums = ws + (size_t)nblk * 2 * Cp;
-    dim3 g1(nblk, (Cp / V + 255) / 256);
-    int g3 = stream_grid(npix * (Cp / V));
+    float* sums = ws + (size_t)BWD_MAX_PARTIALS * 2 * Cp;
+    dim3 g3 = lay_grid(npix, Cp, V, 256 * 8);
     if (dtype == YDL_F32) {
-        bn_bwd_reduce_kernel<float><<<g1, 256, 0, st>>>((const float*)y, ldy, (const float*)dout, lddo, (const float*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp, ppb);
-        bn_bwd_merge_kernel<<<(Cp + 31) / 32, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
+        bn_bwd_reduce_kernel<float><<<g1, 256, 0, st>>>((const float*)y, ldy, (const float*)dout, lddo, (const float*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp);
+        bn_bwd_merge_kernel<<<(Cp + 7) / 8, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
         bn_bwd_apply_kernel<float><<<g3, 256, 0, st>>>((const float*)y, ldy, (const float*)dout, lddo, (const float*)out, ldo, scale, shift, mean, invstd, sums, act, (float*)dy, lddy, (float*)dres, lddr, npix, Cp);
     } else {
-        bn_bwd_reduce_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, lddo, (const bf16_t*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp, ppb);
-        bn_bwd_merge_kernel<<<(Cp + 31) / 32, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
+        bn_bwd_reduce_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, lddo, (const bf16_t*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp);
+        bn_bwd_merge_kernel<<<(Cp + 7) / 8, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
         bn_bwd_apply_kernel<bf16_t><<<g3, 256, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, lddo, (const bf16_t*)out, ldo, scale, shift, mean, invstd, sums, act, (bf16_t*)dy, lddy, (bf16_t*)dres, lddr, npix, Cp);
     }
     YDL_LAUNCH_CHECK();
