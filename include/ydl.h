@@ -74,6 +74,9 @@ int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void*
 
 /* master weights (f32, KRSC [Cout][k*k][Cin]) -> compute copies: w [Cout][kk][Cin_p] and wt [Cin][kk][Cout_p] */
 int ydl_weight_prep(int dtype, const float* master, void* w, void* wt, int Cout, int kk, int Cin, void* stream);
+/* the same for every layer of a model in one launch; desc_dev: device array of nlayers x 8 int64
+ * {master*, w*, wt*, Cout, kk, Cin, 0, 0} */
+int ydl_weight_prep_batched(int dtype, const int64_t* desc_dev, int nlayers, void* stream);
 /* dw [Cout][kk][Cin_p] f32 -> master-layout grad [Cout][kk][Cin] (only needed when Cin_p != Cin) */
 int ydl_wgrad_unpad(const float* dw, float* grad, int Cout, int kk, int Cin, int accumulate, void* stream);
 
@@ -83,7 +86,10 @@ int ydl_wgrad_unpad(const float* dw, float* grad, int Cout, int kk, int Cin, int
 int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, int64_t count, int C,
                     const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
-                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+                    float* mean, float* invstd, float* scale, float* shift,
+                    int replication /* >=1: the logical tensor is the stored one nearest-replicated this many times
+                                       (lazy up-sampling); only the unbiased running_var factor depends on it */,
+                    void* stream);
 /* eval-mode: scale/shift from running statistics */
 int ydl_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, void* stream);
@@ -126,12 +132,13 @@ int ydl_scale_channels(int dtype, const void* x, int ldx, const float* gate /*[N
                        int N, int64_t hw, int C, void* stream);
 
 /* ---- softmax over channels (the yaml models end in nn.Softmax(1)) ----------------------------------- */
-/* x: NHWC compute dtype (C<=32); p: f32 with element strides (sn, sc, sh, sw) — NCHW or NHWC. */
+/* x: NHWC compute dtype (C<=32), stored at (H, W); p: f32 of logical size (N, C, H*rep_h, W*rep_w) with element
+ * strides (sn, sc, sh, sw) — NCHW or NHWC.  rep_* > 1 fuses a nearest up-sampling of the probabilities. */
 int ydl_softmax_fwd(int dtype, const void* x, int ldx, float* p, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
-                    int N, int H, int W, int C, void* stream);
-/* dx = p * (dp - sum_c p*dp) */
+                    int N, int H, int W, int C, int rep_h, int rep_w, void* stream);
+/* dx = p * (dps - sum_c p*dps), dps = dp summed over the rep_h x rep_w replicas of each stored pixel */
 int ydl_softmax_bwd(int dtype, const float* p, const float* dp, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
-                    void* dx, int lddx, int N, int H, int W, int C, void* stream);
+                    void* dx, int lddx, int N, int H, int W, int C, int rep_h, int rep_w, void* stream);
 
 /* ---- CE + 0.5*(Dice|Jaccard) loss ------------------------------------------------------------------ */
 /* ws layout (f32): see ydl_seg_loss_ws_floats.  losses[0..2] = total, ce, overlap-loss (device, no sync). */

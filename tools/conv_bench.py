@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv entry points on selected layer geometries of BASELINE config 2 (dev tool).
+usage: python tools/conv_bench.py [fwd|dgrad|wgrad|all] [--dtype bf16] [--iters 20] [--only IDX,IDX]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from yolo_dual_amd import _lib as L
+
+# (Cin, Cout, k, s, Hout)   bs=16
+LAYERS = [(3, 64, 6, 2, 320), (64, 128, 3, 2, 160), (128, 64, 1, 1, 160), (64, 64, 3, 1, 160), (128, 128, 1, 1, 160),
+          (128, 256, 3, 2, 80), (256, 128, 1, 1, 80), (128, 128, 3, 1, 80), (256, 256, 1, 1, 80), (256, 512, 3, 2, 40),
+          (256, 256, 3, 1, 40), (512, 512, 1, 1, 40), (512, 1024, 3, 2, 20), (512, 512, 3, 1, 20), (2048, 1024, 1, 1, 20),
+          (640, 64, 1, 1, 160), (128, 64, 3, 1, 160), (768, 128, 1, 1, 80), (64, 12, 1, 1, 160)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--bs", type=int, default=16)
+    a = ap.parse_args()
+    dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
+    tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = torch.device("cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sel = [int(v) for v in a.only.split(",")] if a.only else range(len(LAYERS))
+    r8 = lambda v: (v + 7) // 8 * 8
+    for li in sel:
+        Cin, Cout, k, s, Ho = LAYERS[li]
+        p = 2 if k == 6 else k // 2
+        Hi = Ho * s
+        N = a.bs
+        ldx, ldy = r8(Cin), r8(Cout)
+        x = torch.randn(N, Hi, Hi, ldx, device=dev).to(tdt)
+        y = torch.empty(N, Ho, Ho, ldy, device=dev, dtype=tdt)
+        dy = torch.randn(N, Ho, Ho, ldy, device=dev).to(tdt)
+        dx = torch.empty(N, Hi, Hi, ldx, device=dev, dtype=tdt)
+        w = torch.randn(Cout, k * k, ldx, device=dev).to(tdt)
+        wt = torch.randn(Cin, k * k, ldy, device=dev).to(tdt)
+        dw = torch.zeros(Cout, k * k, ldx, device=dev, dtype=torch.float32)
+        g = L.ConvGeom(N, Hi, Hi, Cin, Ho, Ho, Cout, k, s, p, ldx, ldy)
+        gp = ctypes.byref(g)
+        ws = torch.empty(L.lib().ydl_conv_fwd_stats_ws_bytes(gp, dt) // 4, device=dev)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        flops = 2.0 * N * Ho * Ho * Cout * k * k * Cin
+        byts = (N * Hi * Hi * Cin + N * Ho * Ho * Cout) * (2 if a.dtype == "bf16" else 4)
+        ops = {"fwd": lambda: L.call("ydl_conv_fwd", gp, dt, P(x), P(w), P(y), P(ws), st),
+               "dgrad": lambda: L.call("ydl_conv_dgrad", gp, dt, P(dy), P(wt), P(dx), 0, st),
+               "wgrad": lambda: L.call("ydl_conv_wgrad", gp, dt, P(x), P(dy), P(dw), st)}
+        line = f"[{li:2d}] {Cin:5d}->{Cout:5d} k{k}s{s} @{Ho:4d}"
+        for name, fn in ops.items():
+            if a.what not in ("all", name):
+                continue
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            line += f" | {name} {ms * 1e3:7.1f}us {flops / ms / 1e9:5.0f}TF {byts / ms / 1e9:5.2f}TB/s"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()

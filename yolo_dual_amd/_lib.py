@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libydl_hip.so")
+LIB_PATH = os.environ.get("YDL_LIB", os.path.join(_HERE, "lib", "libydl_hip.so"))   # YDL_LIB: dev override for A/B builds
 
 YDL_F32, YDL_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
@@ -37,8 +37,9 @@ SIGNATURES = {
     "ydl_conv_dgrad": (_i, [_G, _i, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_wgrad": (_i, [_G, _i, _vp, _vp, _vp, _vp]),
     "ydl_weight_prep": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ydl_weight_prep_batched": (_i, [_i, _vp, _i, _vp]),
     "ydl_wgrad_unpad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "ydl_bn_finalize": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ydl_bn_finalize": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ydl_bn_eval_coeffs": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "ydl_bn_act_fwd": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i64, _i, _vp]),
     "ydl_bn_bwd_ws_bytes": (_i64, [_i64, _i]),
@@ -52,8 +53,8 @@ SIGNATURES = {
     "ydl_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ydl_nhwc_to_nchw": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ydl_scale_channels": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i64, _i, _vp]),
-    "ydl_softmax_fwd": (_i, [_i, _vp, _i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
-    "ydl_softmax_bwd": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ydl_softmax_fwd": (_i, [_i, _vp, _i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    "ydl_softmax_bwd": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ydl_seg_loss_ws_floats": (_i64, [_i, _i]),
     "ydl_seg_loss_fwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ydl_seg_loss_bwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

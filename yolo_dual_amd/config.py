@@ -1,7 +1,7 @@
 """Process-wide settings of the HIP path."""
 from __future__ import annotations
 
-_STATE = {"dtype": "bf16", "weight_epoch": 0}
+_STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True}
 
 
 def set_compute_dtype(name: str) -> None:
@@ -14,6 +14,15 @@ def set_compute_dtype(name: str) -> None:
 
 def compute_dtype() -> str:
     return _STATE["dtype"]
+
+
+def lazy_upsample() -> bool:
+    """nearest up-sampling by integer factors is kept lazy (point-wise consumers run at the low resolution)"""
+    return _STATE["lazy_upsample"]
+
+
+def set_lazy_upsample(on: bool) -> None:
+    _STATE["lazy_upsample"] = bool(on)
 
 
 def weight_epoch() -> int:

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           long long count, int C, int ldp,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* running_mean, float* running_var,
-                                                          float* mean_o, float* invstd_o, float* scale_o, float* shift_o) {
+                                                          float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int rep) {
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     double tot = 0, m2 = 0, n = 0;
     chan_merge(part, 0, nblocks, block_m, count, c, c < C, ldp, tot, m2, n);
@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         scale_o[c] = sc;
         shift_o[c] = bt - meanf * sc;
         if (running_mean) {
-            double unb = count > 1 ? m2 / (double)(count - 1) : var;
+            // the logical tensor is the stored one replicated `rep` times: M2 and the count scale by rep
+            double nl = (double)count * (double)rep;
+            double unb = nl > 1.0 ? m2 * (double)rep / (nl - 1.0) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
         }
@@ -98,9 +100,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 extern "C" int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, int64_t count, int C,
                                const float* gamma, const float* beta, float eps, float momentum,
                                float* running_mean, float* running_var, float* mean, float* invstd,
-                               float* scale, float* shift, void* stream) {
+                               float* scale, float* shift, int replication, void* stream) {
     YDL_CHECK(stats_ws && mean && invstd && scale && shift, "null pointer");
-    YDL_CHECK(nblocks > 0 && block_m > 0 && count > 0 && C > 0, "bad sizes");
+    YDL_CHECK(nblocks > 0 && block_m > 0 && count > 0 && C > 0 && replication >= 1, "bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int ldp = round_up(C, 8);
     const float* src = stats_ws;
@@ -114,7 +116,7 @@ extern "C" int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, 
         block_m *= MERGE_CHUNK;
     }
     bn_finalize_kernel<<<(C + 31) / 32, 256, 0, st>>>(src, nblocks, block_m, (long long)count, C, ldp, gamma, beta, eps,
-                                                      momentum, running_mean, running_var, mean, invstd, scale, shift);
+                                                      momentum, running_mean, running_var, mean, invstd, scale, shift, replication);
     YDL_LAUNCH_CHECK();
     return 0;
 }

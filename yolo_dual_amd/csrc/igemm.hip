@@ -12,6 +12,9 @@
 // floats of the same 16-byte read (k permuted identically for both operands; exact f32 fmaf chains).
 #include "common.h"
 
+#ifndef YDL_PF
+#define YDL_PF 1     // deeper register prefetch costs an occupancy step on the 128x128 tile (measured slower)
+#endif
 #define ROWB 144      // LDS row stride in bytes (128 data + 16 pad)
 #define MAXTAPS 64
 
@@ -31,6 +34,7 @@ struct IgemmArgs {
     int accumulate;
     int M;            // N*Hg*Wg
     int stats_ld;
+    unsigned bytesA, bytesB;   // buffer extents for the range-checked loads
     signed char dh[MAXTAPS], dw[MAXTAPS];
     unsigned char wt[MAXTAPS];
 };
@@ -50,11 +54,19 @@ template <> struct Mma<float> {
     }
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // BM = pixel tile (64 or 128), BN = output-channel tile (16, 64 or 128).  256 threads = 4 waves, each wave
 // owns BM/4 pixels x all BN channels.
+//
+// Loader (the main loop is issue-bound on VALU if addresses are derived per K-step, so everything that does not
+// depend on k is hoisted): per row a 32-bit byte offset of its (0,0) tap and a 64-bit tap-validity mask are computed
+// once; a K-step adds one table entry (tap delta) and selects "offset or 0xFFFFFFFF" — the loads are raw buffer
+// loads whose range check returns zeros for the padding taps and the tail rows, so there is no branch.
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     constexpr int V = ET<T>::V;
+    constexpr int ES = sizeof(T);
     constexpr int AR = BM / 32;                 // A rows per thread
     constexpr int BR = (BN + 31) / 32;          // B rows per thread
     constexpr int CT = BN / 16;                 // cout tiles per wave
@@ -62,7 +74,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                           // [2][BM][ROWB]
     unsigned char* sB = smem + 2 * BM * ROWB;           // [2][BN][ROWB]
-    int* sTap = (int*)(smem + 2 * (BM + BN) * ROWB);    // [MAXTAPS] packed dh | dw<<8 | wt<<16
+    int* sTapA = (int*)(smem + 2 * (BM + BN) * ROWB);   // [MAXTAPS] byte delta of the tap in A
+    int* sTapB = sTapA + MAXTAPS;                        // [MAXTAPS] byte offset of the tap inside a weight row
+    int* sTapD = sTapB + MAXTAPS;                        // [MAXTAPS] (dh & 0xffff) | (dw << 16)
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -70,18 +84,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int n0 = blockIdx.y * BN;
 
     if (t < MAXTAPS) {
-        int v = 0;
-        if (t < p.ntaps) v = ((int)(unsigned char)p.dh[t]) | (((int)(unsigned char)p.dw[t]) << 8) | (((int)p.wt[t]) << 16);
-        sTap[t] = v;
+        int da = 0, db = 0, dd = 0;
+        if (t < p.ntaps) {
+            da = ((int)p.dh[t] * p.Wi + (int)p.dw[t]) * p.lda * ES;
+            db = (int)p.wt[t] * p.Kc * ES;
+            dd = ((int)p.dh[t] & 0xffff) | ((int)p.dw[t] << 16);
+        }
+        sTapA[t] = da;
+        sTapB[t] = db;
+        sTapD[t] = dd;
     }
 
-    // per-thread loader geometry
     const int q = t & 7;        // chunk column
     const int r = t >> 3;       // row 0..31
-    int ih0[AR], iw0[AR], nb[AR];
+    unsigned rowoff[AR];
+    int ih0[AR], iw0[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int m = m0 + r + 32 * i;
+        rowoff[i] = 0;
+        ih0[i] = -100000;          // tail rows: every tap fails the range test => zeros
+        iw0[i] = 0;
         if (m < p.M) {
             int gw = m % p.Wg;
             int tmp = m / p.Wg;
@@ -89,55 +112,60 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             int n = tmp / p.Hg;
             ih0[i] = gh * p.in_mul;
             iw0[i] = gw * p.in_mul;
-            nb[i] = n * p.Hi;
-        } else {
-            ih0[i] = -100000; iw0[i] = 0; nb[i] = 0;   // always out of range => zeros
+            rowoff[i] = (unsigned)(((n * p.Hi + ih0[i]) * p.Wi + iw0[i]) * p.lda) * (unsigned)ES;
         }
+    }
+    unsigned browoff[BR];
+    bool bvalid[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        int row = r + 32 * i;
+        int co = n0 + row;
+        bvalid[i] = row < BN && co < p.Cout;
+        browoff[i] = (unsigned)co * (unsigned)(p.Ttot * p.Kc * ES);
     }
     const int cpt = p.Kc / V;                       // chunks per tap
     const int nchunks = p.ntaps * cpt;
     const int nk = (nchunks + 7) >> 3;
-    const size_t browstride = (size_t)p.Ttot * p.Kc;
-    const T* Ag = (const T*)p.A;
-    const T* Bg = (const T*)p.B;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
 
-    uint4 ra[AR], rb[BR];
-    __syncthreads();   // sTap visible
+    constexpr int PF = YDL_PF;
+    uint4 ra[PF][AR], rb[PF][BR];
+    __syncthreads();   // tap tables visible
 
-    auto gload = [&](int kk) {
-        int Q = kk * 8 + q;
-        int tap = Q / cpt;
-        int cc = (Q - tap * cpt) * V;
-        bool tv = Q < nchunks;
-        int tp = tv ? sTap[tap] : 0;
-        int dh = (int)(signed char)(tp & 0xff), dw = (int)(signed char)((tp >> 8) & 0xff), wt = (tp >> 16) & 0xff;
+    auto gload = [&](int kk, uint4 (&xa)[AR], uint4 (&xb)[BR]) {
+        const int Q = kk * 8 + q;
+        const int tap = Q / cpt;                      // cpt is a power of two or small: one 32-bit division per K-step
+        const int cc = (Q - tap * cpt) * (V * ES);    // byte offset inside the tap
+        const bool tv = Q < nchunks;
+        const int tidx = tv ? tap : 0;
+        const unsigned da = (unsigned)(sTapA[tidx] + cc);
+        const unsigned db = (unsigned)(sTapB[tidx] + cc);
+        const int dd = sTapD[tidx];
+        const int dh = (int)(short)(dd & 0xffff), dw = dd >> 16;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            int ih = ih0[i] + dh, iw = iw0[i] + dw;
-            bool ok = tv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *(const uint4*)(Ag + ((size_t)(nb[i] + ih) * p.Wi + iw) * p.lda + cc);
-            ra[i] = v;
+            bool ok = tv && (unsigned)(ih0[i] + dh) < (unsigned)p.Hi && (unsigned)(iw0[i] + dw) < (unsigned)p.Wi;
+            unsigned off = ok ? rowoff[i] + da : 0xFFFFFFFFu;
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+            xa[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            int row = r + 32 * i;
-            int co = n0 + row;
-            bool ok = tv && row < BN && co < p.Cout;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *(const uint4*)(Bg + (size_t)co * browstride + (size_t)wt * p.Kc + cc);
-            rb[i] = v;
+            unsigned off = (tv && bvalid[i]) ? browoff[i] + db : 0xFFFFFFFFu;
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+            xb[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    auto sstore = [&](int buf) {
+    unsigned char* const stA = sA + r * ROWB + q * 16;
+    unsigned char* const stB = sB + r * ROWB + q * 16;
+    auto sstore = [&](int buf, const uint4 (&xa)[AR], const uint4 (&xb)[BR]) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i)
-            *(uint4*)(sA + (size_t)buf * BM * ROWB + (r + 32 * i) * ROWB + q * 16) = ra[i];
+        for (int i = 0; i < AR; ++i) *(uint4*)(stA + buf * (BM * ROWB) + i * 32 * ROWB) = xa[i];
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            int row = r + 32 * i;
-            if (row < BN) *(uint4*)(sB + (size_t)buf * BN * ROWB + row * ROWB + q * 16) = rb[i];
-        }
+        for (int i = 0; i < BR; ++i)
+            if (r + 32 * i < BN) *(uint4*)(stB + buf * (BN * ROWB) + i * 32 * ROWB) = xb[i];
     };
 
     f32x4 acc[CT][PT];
@@ -146,30 +174,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    sstore(0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (u < nk || u == 0) gload(u, ra[u], rb[u]);
+    sstore(0, ra[0], rb[0]);
     __syncthreads();
-    int cur = 0;
     const int lrow = lane & 15, lk = (lane >> 4) * 16;
-    for (int kk = 0; kk < nk; ++kk) {
-        if (kk + 1 < nk) gload(kk + 1);
-        const unsigned char* a_base = sB + (size_t)cur * BN * ROWB + lrow * ROWB + lk;
-        const unsigned char* b_base = sA + (size_t)cur * BM * ROWB + (wave * (BM / 4) + lrow) * ROWB + lk;
+    const unsigned char* const fa = sB + lrow * ROWB + lk;
+    const unsigned char* const fb = sA + (wave * (BM / 4) + lrow) * ROWB + lk;
+    for (int kk0 = 0; kk0 < nk; kk0 += PF) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint4 af[CT], bfr[PT];
+        for (int u = 0; u < PF; ++u) {
+            const int kk = kk0 + u;
+            if (kk < nk) {
+                const int cur = kk & 1;
+                if (kk + PF < nk) gload(kk + PF, ra[u], rb[u]);      // set u was consumed by the previous sstore
+                const unsigned char* a_base = fa + cur * (BN * ROWB);
+                const unsigned char* b_base = fb + cur * (BM * ROWB);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * ROWB + s * 64);
+                for (int s = 0; s < 2; ++s) {
+                    uint4 af[CT], bfr[PT];
 #pragma unroll
-            for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * ROWB + s * 64);
+                    for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * ROWB + s * 64);
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+                    for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * ROWB + s * 64);
 #pragma unroll
-                for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+                    for (int c = 0; c < CT; ++c)
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+                }
+                if (kk + 1 < nk) sstore(cur ^ 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                __syncthreads();
+            }
         }
-        if (kk + 1 < nk) sstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
 
     // ---------------- epilogue: store ----------------
@@ -286,7 +323,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 template <typename T, int BM, int BN>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cst + BN - 1) / BN);
-    size_t smem = 2 * (BM + BN) * ROWB + MAXTAPS * sizeof(int);
+    size_t smem = 2 * (BM + BN) * ROWB + 3 * MAXTAPS * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -323,6 +360,17 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = 
     if (c.BM == 64 && c.BN == 128) return launch_igemm<T, 64, 128>(a, st);
     if (c.BM == 64 && c.BN == 64) return launch_igemm<T, 64, 64>(a, st);
     return launch_igemm<T, 64, 16>(a, st);
+}
+
+// byte extents of the gathered tensor and of the weight matrix (raw-buffer range checks: must stay below 4 GiB)
+static int set_extents(IgemmArgs& a, int dtype) {
+    const unsigned long long es = (unsigned long long)esize(dtype);
+    unsigned long long ba = (unsigned long long)a.N * a.Hi * a.Wi * a.lda * es;
+    unsigned long long bb = (unsigned long long)a.Cout * a.Ttot * a.Kc * es;
+    YDL_CHECK(ba < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "tensor larger than 4 GiB: not addressable by the 32-bit buffer loads");
+    a.bytesA = (unsigned)ba;
+    a.bytesB = (unsigned)bb;
+    return 0;
 }
 
 static int check_geom(const ydl_conv_geom* g, int dtype) {
@@ -379,6 +427,7 @@ extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, co
             int tpi = r * g->k + s;
             a.dh[tpi] = (signed char)(r - g->p); a.dw[tpi] = (signed char)(s - g->p); a.wt[tpi] = (unsigned char)tpi;
         }
+    if (int e = set_extents(a, dtype)) return e;
     hipStream_t st = (hipStream_t)stream;
     return dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
 }
@@ -422,6 +471,7 @@ extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy,
                 // no tap reaches this parity class (k < s): the gradient there is zero
                 a.ntaps = 0;
             }
+            if (int e2 = set_extents(a, dtype)) return e2;
             e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
             if (e) return e;
         }

@@ -6,19 +6,24 @@
 #define MAXC 32
 
 // ------------------------------------------------------------------------------------------------------
-// softmax over C (<= 32) channels of an NHWC tensor -> f32 tensor with arbitrary strides
+// softmax over C (<= 32) channels of an NHWC tensor -> f32 tensor with arbitrary strides.
+// (rh, rw) = nearest-replication factors: the output/gradient tensor is (N, C, H*rh, W*rw) while x is stored at
+// (H, W) — the lazily up-sampled point-wise tail (softmax commutes with nearest up-sampling).
+//   forward : one thread per OUTPUT pixel (recomputes the 12 exps; fully coalesced stores)
+//   backward: one thread per STORED pixel, sums dp over its rh x rw replicas, then dx = p*(dps - sum_c p*dps)
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int MC>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ x, int ldx, float* __restrict__ p,
                                                           long long sn, long long sc, long long sh, long long sw,
-                                                          int N, int H, int W, int C) {
-    const long long total = (long long)N * H * W;
+                                                          int N, int H, int W, int C, int rh, int rw) {
+    const int LH = H * rh, LW = W * rw;
+    const long long total = (long long)N * LH * LW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        int w = (int)(i % W);
-        long long t2 = i / W;
-        int h = (int)(t2 % H);
-        int n = (int)(t2 / H);
-        const T* xp = x + (size_t)i * ldx;
+        int w = (int)(i % LW);
+        long long t2 = i / LW;
+        int h = (int)(t2 % LH);
+        int n = (int)(t2 / LH);
+        const T* xp = x + ((size_t)(n * H + h / rh) * W + w / rw) * ldx;
         float v[MC];
         float mx = -INFINITY;
 #pragma unroll
@@ -39,19 +44,27 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
 template <typename T, int MC>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
                                                           long long sn, long long sc, long long sh, long long sw,
-                                                          T* __restrict__ dx, int lddx, int N, int H, int W, int C, int Cp) {
+                                                          T* __restrict__ dx, int lddx, int N, int H, int W, int C, int Cp,
+                                                          int rh, int rw) {
     const long long total = (long long)N * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         int w = (int)(i % W);
         long long t2 = i / W;
         int h = (int)(t2 % H);
         int n = (int)(t2 / H);
-        const long long off = n * sn + h * sh + w * sw;
+        const long long off = n * sn + (long long)(h * rh) * sh + (long long)(w * rw) * sw;
         float pv[MC], gv[MC];
         float dot = 0.f;
 #pragma unroll
         for (int c = 0; c < MC; ++c)
-            if (c < C) { pv[c] = p[off + c * sc]; gv[c] = dp[off + c * sc]; dot += pv[c] * gv[c]; }
+            if (c < C) {
+                pv[c] = p[off + c * sc];
+                float g = 0.f;
+                for (int a = 0; a < rh; ++a)
+                    for (int b = 0; b < rw; ++b) g += dp[off + c * sc + a * sh + b * sw];
+                gv[c] = g;
+                dot += pv[c] * g;
+            }
         T* d = dx + (size_t)i * lddx;
 #pragma unroll
         for (int c = 0; c < MC; ++c)
@@ -67,32 +80,32 @@ static inline int sgrid(long long total) {
 }
 
 extern "C" int ydl_softmax_fwd(int dtype, const void* x, int ldx, float* p, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
-                               int N, int H, int W, int C, void* stream) {
-    YDL_CHECK(x && p && C >= 1 && C <= MAXC && ldx >= C, "bad arguments (C <= 32)");
+                               int N, int H, int W, int C, int rep_h, int rep_w, void* stream) {
+    YDL_CHECK(x && p && C >= 1 && C <= MAXC && ldx >= C && rep_h >= 1 && rep_w >= 1, "bad arguments (C <= 32)");
     hipStream_t st = (hipStream_t)stream;
-    int grid = sgrid((long long)N * H * W);
+    int grid = sgrid((long long)N * H * W * rep_h * rep_w);
     if (dtype == YDL_F32) {
-        if (C <= 16) softmax_fwd_kernel<float, 16><<<grid, 256, 0, st>>>((const float*)x, ldx, p, sn, sc, sh, sw, N, H, W, C);
-        else softmax_fwd_kernel<float, 32><<<grid, 256, 0, st>>>((const float*)x, ldx, p, sn, sc, sh, sw, N, H, W, C);
+        if (C <= 16) softmax_fwd_kernel<float, 16><<<grid, 256, 0, st>>>((const float*)x, ldx, p, sn, sc, sh, sw, N, H, W, C, rep_h, rep_w);
+        else softmax_fwd_kernel<float, 32><<<grid, 256, 0, st>>>((const float*)x, ldx, p, sn, sc, sh, sw, N, H, W, C, rep_h, rep_w);
     } else {
-        if (C <= 16) softmax_fwd_kernel<bf16_t, 16><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, p, sn, sc, sh, sw, N, H, W, C);
-        else softmax_fwd_kernel<bf16_t, 32><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, p, sn, sc, sh, sw, N, H, W, C);
+        if (C <= 16) softmax_fwd_kernel<bf16_t, 16><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, p, sn, sc, sh, sw, N, H, W, C, rep_h, rep_w);
+        else softmax_fwd_kernel<bf16_t, 32><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, p, sn, sc, sh, sw, N, H, W, C, rep_h, rep_w);
     }
     YDL_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int ydl_softmax_bwd(int dtype, const float* p, const float* dp, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
-                               void* dx, int lddx, int N, int H, int W, int C, void* stream) {
+                               void* dx, int lddx, int N, int H, int W, int C, int rep_h, int rep_w, void* stream) {
     const int Cp = round_up(C, 8) <= lddx ? round_up(C, 8) : C;
-    YDL_CHECK(p && dp && dx && C >= 1 && C <= MAXC && lddx >= C, "bad arguments (C <= 32)");
+    YDL_CHECK(p && dp && dx && C >= 1 && C <= MAXC && lddx >= C && rep_h >= 1 && rep_w >= 1, "bad arguments (C <= 32)");
     hipStream_t st = (hipStream_t)stream;
     int grid = sgrid((long long)N * H * W);
     if (dtype == YDL_F32) {
-        if (Cp <= 16) softmax_bwd_kernel<float, 16><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (float*)dx, lddx, N, H, W, C, Cp);
-        else softmax_bwd_kernel<float, 32><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (float*)dx, lddx, N, H, W, C, Cp);
+        if (Cp <= 16) softmax_bwd_kernel<float, 16><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (float*)dx, lddx, N, H, W, C, Cp, rep_h, rep_w);
+        else softmax_bwd_kernel<float, 32><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (float*)dx, lddx, N, H, W, C, Cp, rep_h, rep_w);
     } else {
-        if (Cp <= 16) softmax_bwd_kernel<bf16_t, 16><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (bf16_t*)dx, lddx, N, H, W, C, Cp);
-        else softmax_bwd_kernel<bf16_t, 32><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (bf16_t*)dx, lddx, N, H, W, C, Cp);
+        if (Cp <= 16) softmax_bwd_kernel<bf16_t, 16><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (bf16_t*)dx, lddx, N, H, W, C, Cp, rep_h, rep_w);
+        else softmax_bwd_kernel<bf16_t, 32><<<grid, 256, 0, st>>>(p, dp, sn, sc, sh, sw, (bf16_t*)dx, lddx, N, H, W, C, Cp, rep_h, rep_w);
     }
     YDL_LAUNCH_CHECK();
     return 0;
@@ -107,12 +120,12 @@ extern "C" int ydl_softmax_bwd(int dtype, const float* p, const float* dp, int64
 //   [0, NC)        I      [NC, 2NC) P     [2NC, 3NC) T        (merged sums)
 //   [3NC, 4NC)     aI = d ov/d I   [4NC, 5NC) aP = d ov/d P   (backward coefficients)
 //   [5NC, 5NC+4)   ce_num, ce_den, smooth_num, W = sum_c w_c
-//   [5NC+4, ...)   per-block partials [N][nblk][3C+3]
+//   [5NC+4, ...)   per-block partials [N][nblk][3C+3], then per-image {sumR, ce_num, ce_den, sm_num} [N][4]
 // ------------------------------------------------------------------------------------------------------
 #define LOSS_BLOCKS_PER_IMAGE 128
 
 extern "C" int64_t ydl_seg_loss_ws_floats(int N, int C) {
-    return (int64_t)5 * N * C + 4 + (int64_t)N * LOSS_BLOCKS_PER_IMAGE * (3 * C + 3);
+    return (int64_t)5 * N * C + 4 + (int64_t)N * LOSS_BLOCKS_PER_IMAGE * (3 * C + 3) + (int64_t)4 * N;
 }
 
 __device__ __forceinline__ int target_at(const int64_t* __restrict__ target, int n, int h, int w, int H, int W, int Ht, int Wt,
@@ -192,58 +205,84 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void seg_loss_merge_kernel(float* __restrict__ ws, int N, int C, int nblk, int kind,
-                                                             float ls, float eps, const float* __restrict__ cw,
-                                                             float* __restrict__ losses) {
+// merge level 1: one CTA per image; 8 slices x 32 channels walk the per-CTA partials (16 steps each), LDS-reduce,
+// write I/P/T, the overlap ratio R and its derivatives for this image's (n, c) pairs, and per-image CE partial sums.
+// ws tail used as scratch: [5NC+4+N*nblk*(3C+3) ...) holds per-image {sumR, ce_num, ce_den, sm_num}.
+__global__ __launch_bounds__(256) void seg_loss_merge1_kernel(float* __restrict__ ws, int N, int C, int nblk, int kind,
+                                                              float eps, float* __restrict__ img_part) {
+    const int n = blockIdx.x;
     const int NC = N * C;
-    const float* part = ws + 5 * NC + 4;
-    __shared__ double sR[256];
-    __shared__ double sce[3];
-    double rsum = 0.0;
-    for (int k = threadIdx.x; k < NC; k += blockDim.x) {
-        int n = k / C, c = k % C;
-        double I = 0, P = 0, T = 0;
-        for (int b = 0; b < nblk; ++b) {
-            const float* pb = part + ((size_t)n * nblk + b) * (3 * C + 3);
-            I += pb[c]; P += pb[C + c]; T += pb[2 * C + c];
+    const float* part = ws + 5 * NC + 4 + (size_t)n * nblk * (3 * C + 3);
+    __shared__ double sh[3][8][33];
+    __shared__ double sR[32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double I = 0, P = 0, T = 0;
+    if (cl < C)
+        for (int b = sl; b < nblk; b += 8) {
+            const float* pb = part + (size_t)b * (3 * C + 3);
+            I += pb[cl]; P += pb[C + cl]; T += pb[2 * C + cl];
         }
-        ws[k] = (float)I; ws[NC + k] = (float)P; ws[2 * NC + k] = (float)T;
-        double R, aI, aP;
-        if (kind == YDL_LOSS_DICE) {
-            double den = P + T + eps;
-            R = (2.0 * I + eps) / den;
-            aI = 2.0 / den;
-            aP = -(2.0 * I + eps) / (den * den);
-        } else {
-            double num = I + eps, den = P + T - I + eps;
-            R = num / den;
-            aI = 1.0 / den + num / (den * den);
-            aP = -num / (den * den);
+    sh[0][sl][cl] = I; sh[1][sl][cl] = P; sh[2][sl][cl] = T;
+    __syncthreads();
+    if (sl == 0) {
+        double R = 0.0;
+        if (cl < C) {
+            I = P = T = 0;
+            for (int i = 0; i < 8; ++i) { I += sh[0][i][cl]; P += sh[1][i][cl]; T += sh[2][i][cl]; }
+            const int k = n * C + cl;
+            ws[k] = (float)I; ws[NC + k] = (float)P; ws[2 * NC + k] = (float)T;
+            double aI, aP;
+            if (kind == YDL_LOSS_DICE) {
+                double den = P + T + eps;
+                R = (2.0 * I + eps) / den;
+                aI = 2.0 / den;
+                aP = -(2.0 * I + eps) / (den * den);
+            } else {
+                double num = I + eps, den = P + T - I + eps;
+                R = num / den;
+                aI = 1.0 / den + num / (den * den);
+                aP = -num / (den * den);
+            }
+            ws[3 * NC + k] = (float)(-aI / NC);     // d ov / d I   (ov = 1 - mean R)
+            ws[4 * NC + k] = (float)(-aP / NC);
         }
-        rsum += R;
-        ws[3 * NC + k] = (float)(-aI / NC);     // d ov / d I   (ov = 1 - mean R)
-        ws[4 * NC + k] = (float)(-aP / NC);
+        sR[cl] = R;
     }
-    sR[threadIdx.x] = rsum;
-    if (threadIdx.x < 3) {
-        double a = 0;
-        for (int n = 0; n < N; ++n)
-            for (int b = 0; b < nblk; ++b) a += part[((size_t)n * nblk + b) * (3 * C + 3) + 3 * C + threadIdx.x];
-        sce[threadIdx.x] = a;
+    __syncthreads();
+    // CE partial sums of this image: threads 0..2 of slice 1 would walk nblk entries; spread over the whole CTA
+    double ce[3] = {0, 0, 0};
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const float* pb = part + (size_t)b * (3 * C + 3) + 3 * C;
+        ce[0] += pb[0]; ce[1] += pb[1]; ce[2] += pb[2];
+    }
+    __shared__ double sce[3][4];
+    for (int j = 0; j < 3; ++j) {
+        double v = wave_sum_d(ce[j]);
+        if ((threadIdx.x & 63) == 0) sce[j][threadIdx.x >> 6] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double r = 0;
-        for (int i = 0; i < blockDim.x; ++i) r += sR[i];
-        double ov = 1.0 - r / NC;
-        double Wsum = 0;
-        for (int c = 0; c < C; ++c) Wsum += cw ? cw[c] : 1.0;
-        double ce = (1.0 - ls) * sce[0] / sce[1] + (ls > 0.f ? (double)ls / C * sce[2] / sce[1] : 0.0);
-        ws[5 * NC + 0] = (float)sce[0]; ws[5 * NC + 1] = (float)sce[1]; ws[5 * NC + 2] = (float)sce[2]; ws[5 * NC + 3] = (float)Wsum;
-        losses[0] = (float)(ce + 0.5 * ov);
-        losses[1] = (float)ce;
-        losses[2] = (float)ov;
+        for (int c = 0; c < C; ++c) r += sR[c];
+        img_part[n * 4 + 0] = (float)r;
+        for (int j = 0; j < 3; ++j) img_part[n * 4 + 1 + j] = (float)(sce[j][0] + sce[j][1] + sce[j][2] + sce[j][3]);
     }
+}
+
+__global__ void seg_loss_merge2_kernel(float* __restrict__ ws, int N, int C, float ls, const float* __restrict__ cw,
+                                       const float* __restrict__ img_part, float* __restrict__ losses) {
+    if (threadIdx.x != 0) return;
+    const int NC = N * C;
+    double r = 0, a = 0, b = 0, d = 0;
+    for (int n = 0; n < N; ++n) { r += img_part[n * 4]; a += img_part[n * 4 + 1]; b += img_part[n * 4 + 2]; d += img_part[n * 4 + 3]; }
+    double ov = 1.0 - r / NC;
+    double Wsum = 0;
+    for (int c = 0; c < C; ++c) Wsum += cw ? cw[c] : 1.0;
+    double ce = (1.0 - ls) * a / b + (ls > 0.f ? (double)ls / C * d / b : 0.0);
+    ws[5 * NC + 0] = (float)a; ws[5 * NC + 1] = (float)b; ws[5 * NC + 2] = (float)d; ws[5 * NC + 3] = (float)Wsum;
+    losses[0] = (float)(ce + 0.5 * ov);
+    losses[1] = (float)ce;
+    losses[2] = (float)ov;
 }
 
 template <int MC>
@@ -318,7 +357,9 @@ extern "C" int ydl_seg_loss_fwd(const float* pred, int64_t sn, int64_t sc, int64
     else
         seg_loss_fwd_kernel<32><<<grid, 256, 0, st>>>(pred, sn, sc, sh, sw, target, Ht, Wt, class_weights, C, H, W, sth, stw,
                                                       ws + (size_t)5 * N * C + 4);
-    seg_loss_merge_kernel<<<1, 256, 0, st>>>(ws, N, C, LOSS_BLOCKS_PER_IMAGE, kind, label_smoothing, eps, class_weights, losses);
+    float* img_part = ws + (size_t)5 * N * C + 4 + (size_t)N * LOSS_BLOCKS_PER_IMAGE * (3 * C + 3);
+    seg_loss_merge1_kernel<<<N, 256, 0, st>>>(ws, N, C, LOSS_BLOCKS_PER_IMAGE, kind, eps, img_part);
+    seg_loss_merge2_kernel<<<1, 64, 0, st>>>(ws, N, C, label_smoothing, class_weights, img_part, losses);
     YDL_LAUNCH_CHECK();
     return 0;
 }

@@ -41,6 +41,44 @@ extern "C" int ydl_weight_prep(int dtype, const float* master, void* w, void* wt
     return 0;
 }
 
+// all layers of a model in ONE launch: blockIdx.y = layer, descriptors live in device memory
+// desc[l] = {master*, w*, wt*, Cout, kk, Cin, 0, 0} as 8 x int64
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const long long* __restrict__ desc) {
+    const long long* d = desc + (size_t)blockIdx.y * 8;
+    const float* master = (const float*)d[0];
+    T* w = (T*)d[1];
+    T* wt = (T*)d[2];
+    const int Cout = (int)d[3], kk = (int)d[4], Cin = (int)d[5];
+    const int Cin_p = (Cin + 7) / 8 * 8, Cout_p = (Cout + 7) / 8 * 8;
+    const long long n1 = (long long)Cout * kk * Cin_p;
+    const long long n2 = (long long)Cin * kk * Cout_p;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            int ci = (int)(i % Cin_p);
+            long long r = i / Cin_p;
+            ET<T>::st(w + i, ci < Cin ? master[r * Cin + ci] : 0.f);
+        } else {
+            long long j = i - n1;
+            int co = (int)(j % Cout_p);
+            long long r = j / Cout_p;
+            int t = (int)(r % kk);
+            int ci = (int)(r / kk);
+            ET<T>::st(wt + j, co < Cout ? master[((long long)co * kk + t) * Cin + ci] : 0.f);
+        }
+    }
+}
+
+extern "C" int ydl_weight_prep_batched(int dtype, const int64_t* desc_dev, int nlayers, void* stream) {
+    YDL_CHECK(desc_dev && nlayers > 0, "bad arguments");
+    dim3 grid(128, nlayers);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) weight_prep_batched_kernel<float><<<grid, 256, 0, st>>>((const long long*)desc_dev);
+    else weight_prep_batched_kernel<bf16_t><<<grid, 256, 0, st>>>((const long long*)desc_dev);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void wgrad_unpad_kernel(const float* __restrict__ dw, float* __restrict__ grad, long long rows, int Cin, int Cin_p, int accumulate) {
     const long long total = rows * Cin;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

@@ -161,7 +161,7 @@ class _YamlSegModel(YdlModule):
             inp = [outs[f] for f in from_] if isinstance(from_, list) else outs[from_]
             if isinstance(layer, Softmax):
                 H, W = self.img_size
-                if i == n_head - 1 and (inp.H, inp.W) == (H, W):
+                if i == n_head - 1 and (inp.LH, inp.LW) == (H, W):
                     p = tape.softmax_nchw(inp)          # final layer, already at img_size: write NCHW f32 directly
                     tape.ext = (inp, p)
                     return p
@@ -170,7 +170,7 @@ class _YamlSegModel(YdlModule):
                 x = layer._fwd(tape, inp)
             outs.append(x)
         H, W = self.img_size
-        if (x.H, x.W) != (H, W):                            # T7: always resized to the hard-coded img_size
+        if (x.LH, x.LW) != (H, W):                          # T7: always resized to the hard-coded img_size
             x = tape.resize(x, H, W, L.RESIZE_BILINEAR)
         return x
 

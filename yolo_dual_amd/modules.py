@@ -51,6 +51,7 @@ class _Region(torch.autograd.Function):
                                "(move the module and its inputs to cuda)")
         record = any(ctx.needs_input_grad[2:])
         tape = Tape(config.compute_dtype(), dev, fn.training, record)
+        refresh_weights(fn, tape)
         vs = [tape.input_nchw(t) for t in ins]
         for i, v in enumerate(vs):
             v.need = bool(ctx.needs_input_grad[2 + i])
@@ -58,8 +59,8 @@ class _Region(torch.autograd.Function):
         if isinstance(res, torch.Tensor):           # region already produced its external output (softmax head)
             out_t, out_v = res, None
         else:
-            out_v = res
-            out_t = tape.export_nchw(res)
+            out_v = tape.materialize(res)           # a lazily up-sampled result becomes real at the region edge
+            out_t = tape.export_nchw(out_v)
         ctx.tape, ctx.vs, ctx.out_v, ctx.fn = tape, vs, out_v, fn
         ctx.n_extra = len(tensors) - n_in
         return out_t
@@ -75,6 +76,32 @@ class _Region(torch.autograd.Function):
         gins = [tape.grad_nchw(v) if v.need else None for v in ctx.vs]
         ctx.tape = None
         return (None, None, *gins, *([None] * ctx.n_extra))
+
+
+def refresh_weights(fn: nn.Module, tape: Tape) -> None:
+    """one batched launch re-deriving the compute-layout weights of every stale Conv under ``fn``"""
+    convs = getattr(fn, "_ydl_convs", None)
+    if convs is None:
+        convs = [m for m in fn.modules() if isinstance(m, Conv)]
+        fn._ydl_convs = convs
+    stale = [m for m in convs if m._wcache.get("key") != m._wkey(tape)]
+    if len(stale) < 2:
+        return
+    rows, keep = [], []
+    for m in stale:
+        master = m._master_krsc()
+        w, wt = m._wbuffers(tape, master)
+        keep.append(master)
+        rows.append([master.data_ptr(), w.data_ptr(), wt.data_ptr(), m.c2, m.k * m.k, m.c1, 0, 0])
+    sig = tuple(r[0] for r in rows) + tuple(r[1] for r in rows) + (tape.dname,)
+    cache = getattr(fn, "_ydl_wdesc", None)
+    if cache is None or cache[0] != sig:
+        desc = torch.tensor(rows, dtype=torch.int64).to(tape.device)
+        fn._ydl_wdesc = (sig, desc)
+    desc = fn._ydl_wdesc[1]
+    L.call("ydl_weight_prep_batched", tape.dt, _p(desc), len(rows), _stream())
+    for m in stale:
+        m._wcache["key"] = m._wkey(tape)
 
 
 def run_region(fn: nn.Module, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -175,24 +202,30 @@ class Conv(YdlModule):
                 w = w.contiguous()
         return w
 
-    def compute_weights(self, tape: Tape):
+    def _wkey(self, tape: Tape):
         wp = self.conv.weight
-        key = (tape.dname, wp.data_ptr(), wp._version, config.weight_epoch())
-        hit = self._wcache.get("key")
-        if hit == key:
-            return self._wcache["w"], self._wcache["wt"]
-        master = self._master_krsc()
+        return (tape.dname, wp.data_ptr(), wp._version, config.weight_epoch())
+
+    def _wbuffers(self, tape: Tape, master: torch.Tensor):
         kk = self.k * self.k
-        cin_p, cout_p = round_up(self.c1, 8), round_up(self.c2, 8)
         dev = master.device
         w = self._wcache.get("w")
         if w is None or self._wcache.get("dname") != tape.dname or w.device != dev:
-            w = torch.empty((self.c2, kk, cin_p), dtype=tape.tdt, device=dev)
-            wt = torch.empty((self.c1, kk, cout_p), dtype=tape.tdt, device=dev)
-        else:
-            wt = self._wcache["wt"]
-        L.call("ydl_weight_prep", tape.dt, _p(master), _p(w), _p(wt), self.c2, kk, self.c1, _stream())
-        self._wcache = {"key": key, "w": w, "wt": wt, "dname": tape.dname}
+            w = torch.empty((self.c2, kk, round_up(self.c1, 8)), dtype=tape.tdt, device=dev)
+            wt = torch.empty((self.c1, kk, round_up(self.c2, 8)), dtype=tape.tdt, device=dev)
+            self._wcache.update(w=w, wt=wt, dname=tape.dname, key=None)
+        return self._wcache["w"], self._wcache["wt"]
+
+    def compute_weights(self, tape: Tape):
+        """compute-dtype copies w [Cout][taps][Cin_p] / wt [Cin][taps][Cout_p] of the f32 KRSC master weight, refreshed
+        when the parameter changed (torch version counter, or the epoch the fused optimizer bumps)"""
+        key = self._wkey(tape)
+        if self._wcache.get("key") == key:
+            return self._wcache["w"], self._wcache["wt"]
+        master = self._master_krsc()
+        w, wt = self._wbuffers(tape, master)
+        L.call("ydl_weight_prep", tape.dt, _p(master), _p(w), _p(wt), self.c2, self.k * self.k, self.c1, _stream())
+        self._wcache["key"] = key
         return w, wt
 
     def coeffs(self, device):
@@ -397,6 +430,12 @@ class Upsample(YdlModule):
         return int(math.floor(x.H * sh)), int(math.floor(x.W * sw))
 
     def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None) -> Var:
+        if self.mode == "nearest" and self.size is None and out is None and config.lazy_upsample():
+            sf = self.scale_factor
+            sh, sw = (sf, sf) if not isinstance(sf, (tuple, list)) else sf
+            if float(sh).is_integer() and float(sw).is_integer() and sh >= 1 and sw >= 1:
+                return tape.upsample_lazy(x, int(sh), int(sw))     # no memory traffic; see tape.Var.rep
+        x = tape.materialize(x)
         Ho, Wo = self._out_size(x)
         if self.mode == "nearest":
             # ATen passes 1/scale_factor as the index scale when a scale_factor was given
@@ -479,6 +518,7 @@ class SegmentHead(YdlModule):
     def _fwd(self, tape: Tape, feats: Sequence[Var]) -> Var:
         if len(feats) != len(self.lateral_convs):
             raise ValueError(f"feature count mismatch: expected {len(self.lateral_convs)}, got {len(feats)}")
+        feats = [tape.materialize(f) for f in feats]
         H, W = feats[0].H, feats[0].W
         cat = tape.new(feats[0].N, 128 * len(feats), H, W)
         for i, (f, lat, up) in enumerate(zip(feats, self.lateral_convs, self.up_samples)):

@@ -34,7 +34,7 @@ def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
 
 class Var:
     """A NHWC activation: ``t`` is a logical (N,C,H,W) torch view whose memory is [N][H][W][ld] with c fastest."""
-    __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt")
+    __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt", "rep", "alias")
 
     def __init__(self, tape: "Tape", t: torch.Tensor, ld: int, need: bool, parent: Optional["Var"] = None, c0: int = 0):
         self.tape = tape
@@ -48,17 +48,42 @@ class Var:
         self.parent = parent
         self.c0 = c0
         self.children: List["Var"] = []
+        # lazy nearest up-sampling: the LOGICAL tensor is this (stored) one replicated rep[0] x rep[1] times.
+        # Point-wise ops (1x1 conv, BN, activation, channel softmax) commute with it and run at the stored size;
+        # gradients of a lazy Var are kept as the SUM over the replicas, which makes every backward formula of
+        # those ops identical to the un-replicated one.
+        self.rep = (1, 1)
+        self.alias = False      # full-range view of ``parent`` (lazy / materialise views): shares its gradient state
+
+    def root(self) -> "Var":
+        v = self
+        while v.alias:
+            v = v.parent
+        return v
 
     @property
     def npix(self) -> int:
         return self.N * self.H * self.W
 
+    @property
+    def LH(self) -> int:
+        return self.H * self.rep[0]
+
+    @property
+    def LW(self) -> int:
+        return self.W * self.rep[1]
+
+    @property
+    def lazy(self) -> bool:
+        return self.rep != (1, 1)
+
     def is_set(self) -> bool:
-        return self.gset or (self.parent is not None and self.parent.is_set())
+        v = self.root()
+        return v.gset or (v.parent is not None and v.parent.is_set())
 
     def aligned(self) -> bool:
         """16-byte channel alignment of a slice (whole buffers always are): required by the vector kernels"""
-        return self.parent is None or (self.c0 % 8 == 0 and self.C % 8 == 0 and self.parent.aligned())
+        return self.parent is None or self.alias and self.parent.aligned() or (self.c0 % 8 == 0 and self.C % 8 == 0 and self.parent.aligned())
 
     def slice(self, c0: int, c1: int) -> "Var":
         v = Var(self.tape, self.t[:, c0:c1], self.ld, self.need, parent=self, c0=c0)
@@ -95,6 +120,7 @@ class Tape:
 
     def _gbuf(self, v: Var) -> torch.Tensor:
         """gradient buffer of v (a slice shares its parent's buffer)"""
+        v = v.root()
         if v.g is None:
             if v.parent is not None:
                 pg = self._gbuf(v.parent)
@@ -105,6 +131,7 @@ class Tape:
 
     def grad_target(self, v: Var) -> (torch.Tensor, int):
         """(buffer, accumulate) for a kernel about to write d/dv; marks v as set."""
+        v = v.root()
         g = self._gbuf(v)
         acc = 1 if v.is_set() else 0
         if not acc and v.children and any(c.gset for c in v.children):
@@ -135,7 +162,25 @@ class Tape:
         L.call("ydl_nchw_to_nhwc", self.dt, _p(x), _p(v.t), v.ld, N, C, H, W, _stream())
         return v
 
+    # ------------------------------------------------------------------ lazy nearest up-sampling
+    def upsample_lazy(self, x: Var, fh: int, fw: int) -> Var:
+        """nearest up-sampling by integer factors without touching memory (see Var.rep)"""
+        v = Var(self, x.t, x.ld, x.need, parent=x, c0=0)
+        v.alias = True
+        v.rep = (x.rep[0] * fh, x.rep[1] * fw)
+        return v
+
+    def materialize(self, x: Var, out: Optional[Var] = None) -> Var:
+        """turn a lazy Var into a real (LH, LW) tensor (nearest replication kernel; backward sums the replicas)"""
+        if not x.lazy:
+            return x if out is None else self.copy(x, out)
+        fh, fw = x.rep
+        plain = Var(self, x.t, x.ld, x.need, parent=x, c0=0)
+        plain.alias = True
+        return self.resize(plain, x.H * fh, x.W * fw, L.RESIZE_NEAREST, 1.0 / fh, 1.0 / fw, out=out)
+
     def export_nchw(self, v: Var) -> torch.Tensor:
+        v = self.materialize(v)
         out = torch.empty((v.N, v.C, v.H, v.W), dtype=torch.float32, device=self.device)
         L.call("ydl_nhwc_to_nchw", v.dt, _p(v.t), v.ld, _p(out), v.N, v.C, v.H, v.W, 0, _stream())
         return out
@@ -169,6 +214,14 @@ class Tape:
         Cout, Cin = m.c2, m.c1
         if x.C != Cin:
             raise RuntimeError(f"Conv layer input channel mismatch: got {x.C}, weight expects {Cin}")
+        rep = 1
+        if x.lazy:
+            if k == 1 and s == 1 and p == 0 and res is None and out is None:
+                rep = x.rep[0] * x.rep[1]           # point-wise: run at the stored size, stay lazy
+            else:
+                x = self.materialize(x)
+        if res is not None and res.lazy:
+            res = self.materialize(res)
         if not x.aligned():                       # odd channel split: stage through an aligned buffer (cold path)
             x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need))
         if res is not None and not res.aligned():
@@ -181,6 +234,7 @@ class Tape:
         y = self.new(x.N, Cout, Ho, Wo)
         if out is None:
             out = self.new(x.N, Cout, Ho, Wo)
+            out.rep = x.rep
         elif (out.N, out.C, out.H, out.W) != (x.N, Cout, Ho, Wo):
             raise RuntimeError("conv_bn_act: output slice has the wrong shape")
         geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld)
@@ -196,7 +250,7 @@ class Tape:
             L.call("ydl_bn_finalize", _p(ws), L.lib().ydl_conv_fwd_grid_m(gp), L.lib().ydl_conv_fwd_block_m(gp),
                    x.N * Ho * Wo, Cout, _p(m.bn.weight), _p(m.bn.bias), m.bn.eps, m.bn.momentum,
                    _p(m.bn.running_mean), _p(m.bn.running_var), _p(cf["mean"]), _p(cf["invstd"]),
-                   _p(cf["scale"]), _p(cf["shift"]), st)
+                   _p(cf["scale"]), _p(cf["shift"]), rep, st)
         else:
             L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), None, st)
             L.call("ydl_bn_eval_coeffs", Cout, _p(m.bn.weight), _p(m.bn.bias), _p(m.bn.running_mean),
@@ -249,6 +303,7 @@ class Tape:
 
     # ------------------------------------------------------------------ pooling / resize / copies
     def maxpool(self, x: Var, k: int, s: int, p: int, out: Optional[Var] = None) -> Var:
+        x = self.materialize(x)
         Ho = (x.H + 2 * p - k) // s + 1
         Wo = (x.W + 2 * p - k) // s + 1
         if not x.aligned():
@@ -274,6 +329,7 @@ class Tape:
     def resize(self, x: Var, Ho: int, Wo: int, mode: int, scale_h: float = 0.0, scale_w: float = 0.0,
                out: Optional[Var] = None) -> Var:
         """mode: L.RESIZE_NEAREST / RESIZE_BILINEAR (align_corners=False) / RESIZE_BILINEAR_AC (True)."""
+        x = self.materialize(x)
         if not x.aligned():
             x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need, f32=(x.dt == L.YDL_F32)))
         if out is not None and not out.aligned():
@@ -294,6 +350,8 @@ class Tape:
 
     def copy(self, x: Var, out: Var) -> Var:
         """out[:] = x (channel-slice aware); backward adds d(out) into d(x)."""
+        if x.lazy:
+            return self.materialize(x, out=out)
         L.call("ydl_copy2d", x.dt, _p(x.t), x.ld, _p(out.t), out.ld, x.npix, x.C, 0, _stream())
         if self.record:
             def bw():
@@ -307,13 +365,13 @@ class Tape:
     def concat(self, xs: Sequence[Var], align: bool = True) -> Var:
         """Concat along channels with the reference's auto-align (bilinear, align_corners=False, to the first
         input's size) — seg_diceloss_yolov5.py:484-507.  Each source is written straight into its slice."""
-        H, W = xs[0].H, xs[0].W
+        H, W = xs[0].LH, xs[0].LW
         Ct = sum(v.C for v in xs)
         cat = self.new(xs[0].N, Ct, H, W, f32=(xs[0].dt == L.YDL_F32))
         c0 = 0
         for v in xs:
             sl = cat.slice(c0, c0 + v.C)
-            if (v.H, v.W) == (H, W):
+            if (v.LH, v.LW) == (H, W):
                 self.copy(v, sl)
             elif align:
                 self.resize(v, H, W, L.RESIZE_BILINEAR, out=sl)
@@ -326,8 +384,9 @@ class Tape:
     def softmax(self, x: Var) -> Var:
         """nn.Softmax(1) into an f32 NHWC Var (probabilities stay f32 even in bf16 mode)."""
         out = self.new(x.N, x.C, x.H, x.W, zero=True, f32=True)
+        out.rep = x.rep                                   # point-wise: stays lazy
         sn, sc, sh, sw = out.t.stride()
-        L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(out.t), sn, sc, sh, sw, x.N, x.H, x.W, x.C, _stream())
+        L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(out.t), sn, sc, sh, sw, x.N, x.H, x.W, x.C, 1, 1, _stream())
         if self.record:
             def bw():
                 if not out.is_set() or not x.need:
@@ -335,16 +394,18 @@ class Tape:
                 dp = self._gbuf(out)
                 gx, acc = self.grad_target(x)
                 assert acc == 0, "softmax input must have a single consumer"
-                L.call("ydl_softmax_bwd", x.dt, _p(out.t), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, _stream())
+                L.call("ydl_softmax_bwd", x.dt, _p(out.t), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, 1, 1,
+                       _stream())
             self.bw.append(bw)
         return out
 
     def softmax_nchw(self, x: Var) -> torch.Tensor:
         """nn.Softmax(1) producing the region's external output directly: f32 NCHW contiguous (no extra pass).
         The region owner must call softmax_nchw_backward with the incoming gradient."""
-        p = torch.empty((x.N, x.C, x.H, x.W), dtype=torch.float32, device=self.device)
+        p = torch.empty((x.N, x.C, x.LH, x.LW), dtype=torch.float32, device=self.device)
         sn, sc, sh, sw = p.stride()
-        L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(p), sn, sc, sh, sw, x.N, x.H, x.W, x.C, _stream())
+        L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(p), sn, sc, sh, sw, x.N, x.H, x.W, x.C, x.rep[0], x.rep[1],
+               _stream())
         return p
 
     def softmax_nchw_backward(self, x: Var, p: torch.Tensor, dp: torch.Tensor) -> None:
@@ -354,9 +415,11 @@ class Tape:
         gx, acc = self.grad_target(x)
         assert acc == 0
         sn, sc, sh, sw = p.stride()
-        L.call("ydl_softmax_bwd", x.dt, _p(p), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, _stream())
+        L.call("ydl_softmax_bwd", x.dt, _p(p), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, x.rep[0], x.rep[1],
+               _stream())
 
     def scale_channels(self, x: Var, gate: torch.Tensor) -> Var:
+        x = self.materialize(x)
         out = self.new_like(x)
         L.call("ydl_scale_channels", x.dt, _p(x.t), x.ld, _p(gate), _p(out.t), out.ld, x.N, x.H * x.W, x.C, _stream())
         return out
