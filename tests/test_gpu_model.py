@@ -123,8 +123,11 @@ def test_bf16_tracks_f32():
     assert l2_err(res["bf16"][2], res["f32"][2]) < 0.4        # stem weight gradient: the longest bf16 chain
 
 
-def test_wgrad_transposed_read_matches_scalar_read():
-    """A/B the ds_read_b64_tr_b16 operand path of the bf16 wgrad kernel against the scalar-LDS-read path."""
+@pytest.mark.parametrize("shape", [(2, 64, 96, 20, 24), (2, 64, 64, 320, 328)])
+def test_wgrad_transposed_read_matches_scalar_read(shape):
+    """A/B the ds_read_b64_tr_b16 operand paths of the bf16 wgrad kernels (64x64-tile kernel; 128-wide pipelined kernel,
+    selected for M >= 200k pixels) against the scalar-LDS-read kernel."""
+    N, C1, C2, H, W = shape
     import yolo_dual_amd as ydl
     from yolo_dual_amd import _lib as L
     ydl.set_compute_dtype("bf16")
@@ -132,16 +135,16 @@ def test_wgrad_transposed_read_matches_scalar_read():
     res = []
     for tr in (1, 0):
         L.lib().ydl_debug_set(0, tr)
-        m = ydl.Conv(64, 96, 3, 1).cuda().train()
+        m = ydl.Conv(C1, C2, 3, 1).cuda().train()
         torch.manual_seed(1)
         with torch.no_grad():
             m.conv.weight.normal_(0, 0.05)
-        x = torch.randn(2, 64, 20, 24, device="cuda", generator=torch.Generator("cuda").manual_seed(2)).requires_grad_(True)
+        x = torch.randn(N, C1, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(2)).requires_grad_(True)
         out = m(x)
         out.square().sum().backward()
         res.append(m.conv.weight.grad.detach().clone())
     L.lib().ydl_debug_set(0, 1)
-    assert rel_err(res[0].cpu(), res[1].cpu()) < 1e-5       # same products, different atomic order only
+    assert rel_err(res[0].cpu(), res[1].cpu()) < 1e-4       # same products, different split-K / atomic order only
 
 
 def test_full_size_properties():

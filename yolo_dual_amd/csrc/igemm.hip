@@ -639,8 +639,196 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         }
 }
 
+// ======================================================================================================
+// wgrad, bf16 fast path: 128-byte... no: 256-byte rows.  CTA tile = TCO output channels x 128 flattened-K columns,
+// 64 pixels per stage, register-prefetched (the next stage's global loads are in flight while the MFMAs of the
+// current one run), pixel decode by multiply-shift (no integer division in the loop).
+//   TCO = 128: waves 2 (cout) x 2 (j), each 64 x 64 = 4 x 4 MFMA tiles;  TCO = 64: waves 1 x 4, each 64 x 32.
+// ======================================================================================================
+#define W2_ROWB 272      // 256 data + 16 pad bytes per LDS row
+
+struct Wgrad2Args {
+    const bf16_t* X; const bf16_t* dY; float* dW;
+    int N, Hi, Wi, ldx, Kc;
+    int Ho, Wo, ldy, Cout;
+    int k, s, p;
+    int M, chunk, ntaps;
+    unsigned long long magicW, magicHW;   // ceil(2^40 / Wo), ceil(2^40 / (Ho*Wo))
+    unsigned bytesX, bytesY;
+};
+
+__device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
+    return (unsigned)(((unsigned long long)n * magic) >> 40);
+}
+
+template <int TCO>
+__global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
+    constexpr int WCO = TCO / 64;              // waves along cout
+    constexpr int WJ = 4 / WCO;                // waves along j
+    constexpr int JW = 128 / WJ;               // j columns per wave
+    constexpr int NA = 4;                      // cout tiles per wave (64 / 16)
+    constexpr int NB = JW / 16;                // j tiles per wave
+    constexpr int YCH = TCO / 8;               // 16-byte chunks per dY tile row
+    constexpr int YR = (64 * YCH) / 256;       // dY rows per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sY = smem;                              // [2][64][W2_ROWB]
+    unsigned char* sX = smem + 2 * 64 * W2_ROWB;           // [2][64][W2_ROWB]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wi = wave / WJ, wj = wave % WJ;
+    const int jt = blockIdx.x, ct = blockIdx.y;
+    const int cpt = p.Kc / 8;
+    const int nchunks = p.ntaps * cpt;
+    // X tile: 16 chunks per row, 16 rows per pass, 4 passes;  this thread's chunk (=> tap, channel) is fixed
+    const int xq = t & 15, xr = t >> 4;
+    const int Q = jt * 16 + xq;
+    const bool qv = Q < nchunks;
+    const int tap = qv ? Q / cpt : 0;
+    const int cc = (Q - tap * cpt) * 8;
+    const int dh = tap / p.k - p.p, dw = tap % p.k - p.p;
+    // dY tile: YCH chunks per row
+    const int yq = t % YCH, yr = t / YCH;
+    const int co_chunk = ct * TCO + yq * 8;
+    const bool yv = co_chunk < p.Cout;
+    const int pbeg = blockIdx.z * p.chunk;
+    const int pend = min(p.M, pbeg + p.chunk);
+    const int HoWo = p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.bytesX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, p.bytesY, 0x00020000);
+
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 vy[YR], vx[4];
+    auto gload = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < YR; ++i) {
+            int m = p0 + yr + (256 / YCH) * i;
+            unsigned off = (yv && m < pend) ? (unsigned)(m * p.ldy + co_chunk) * 2u : 0xFFFFFFFFu;
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
+            vy[i] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = p0 + xr + 16 * i;
+            unsigned n = fastdiv40((unsigned)m, p.magicHW);
+            unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+            unsigned ho = fastdiv40(rem, p.magicW);
+            unsigned wo = rem - ho * (unsigned)p.Wo;
+            int ih = (int)ho * p.s + dh, iw = (int)wo * p.s + dw;
+            bool ok = qv && m < pend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            unsigned off = ok ? (unsigned)(((int)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * 2u : 0xFFFFFFFFu;
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+            vx[i] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < YR; ++i)
+            *(uint4*)(sY + buf * (64 * W2_ROWB) + (yr + (256 / YCH) * i) * W2_ROWB + yq * 16) = vy[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(uint4*)(sX + buf * (64 * W2_ROWB) + (xr + 16 * i) * W2_ROWB + xq * 16) = vx[i];
+    };
+
+    gload(pbeg);
+    sstore(0);
+    __syncthreads();
+    const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    int cur = 0;
+    for (int p0 = pbeg; p0 < pend; p0 += 64) {
+        const bool more = p0 + 64 < pend;
+        if (more) gload(p0 + 64);
+        const unsigned char* by = sY + cur * (64 * W2_ROWB) + (g * 8 + lq) * W2_ROWB + (wi * 64 + lp * 4) * 2;
+        const unsigned char* bx = sX + cur * (64 * W2_ROWB) + (g * 8 + lq) * W2_ROWB + (wj * JW + lp * 4) * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[NA], bfv[NB];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const unsigned char* base = by + ks * 32 * W2_ROWB + a * 32;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * W2_ROWB));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                af[a] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const unsigned char* base = bx + ks * 32 * W2_ROWB + b * 32;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * W2_ROWB));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                bfv[b] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) Mma<bf16_t>::run(af[a], bfv[b], acc[a][b]);
+        }
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const size_t wrow = (size_t)p.ntaps * p.Kc;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            int j = jt * 128 + wj * JW + b * 16 + (lane & 15);
+            if (j < (int)wrow) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int co = ct * TCO + wi * 64 + a * 16 + (lane >> 4) * 4 + e;
+                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * wrow + j, acc[a][b][e]);
+                }
+            }
+        }
+}
+
+static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, float* dw, hipStream_t st) {
+    Wgrad2Args a{};
+    a.X = (const bf16_t*)x; a.dY = (const bf16_t*)dy; a.dW = dw;
+    a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = round_up(g->Cin, 8);
+    a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
+    a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = g->k * g->k;
+    a.M = g->N * g->Ho * g->Wo;
+    unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * 2ull;
+    unsigned long long by = (unsigned long long)a.M * g->ldy * 2ull;
+    YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M < (1ull << 21),
+              "tensor too large for the 32-bit wgrad addressing");
+    a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by;
+    a.magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
+    a.magicHW = ((1ull << 40) + (unsigned long long)g->Ho * g->Wo - 1) / ((unsigned long long)g->Ho * g->Wo);
+    const int TCO = g->Cout > 64 ? 128 : 64;
+    int jtiles = (a.ntaps * a.Kc + 127) / 128;
+    int ctiles = (g->Cout + TCO - 1) / TCO;
+    long tiles = (long)jtiles * ctiles;
+    int stages = (a.M + 63) / 64;
+    int splits = (int)((1024 + tiles - 1) / tiles);
+    if (splits > stages / 4) splits = stages / 4;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    int per = (stages + splits - 1) / splits;
+    a.chunk = per * 64;
+    splits = (a.M + a.chunk - 1) / a.chunk;
+    dim3 grid(jtiles, ctiles, splits);
+    size_t smem = 4 * 64 * W2_ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)wgrad2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    if (TCO == 128) wgrad2_kernel<128><<<grid, 256, smem, st>>>(a);
+    else wgrad2_kernel<64><<<grid, 256, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
 static int g_wgrad_tr = 1;
-// debug knobs (tests A/B the transposed-read path against the scalar-read path): key 0 = wgrad tr-read on/off
+// debug knobs: key 0 = bf16 wgrad path: 1 (default) 128-wide tr-read kernel, 2 64x64 tr-read kernel, 0 64x64 scalar-LDS-read kernel
 extern "C" void ydl_debug_set(int key, int val) { if (key == 0) g_wgrad_tr = val; }
 
 extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream) {
@@ -669,6 +857,9 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     splits = (a.M + a.chunk - 1) / a.chunk;
     dim3 grid(jtiles, ctiles, splits);
     hipStream_t st = (hipStream_t)stream;
+    // measured on MI355X: the 128-wide pipelined kernel wins on the large-M layers (>= 160x160 at bs 16), the small
+    // 64x64-tile kernel (8 CTAs/CU) wins where M is small and the grid of big tiles would be latency-bound
+    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && a.M >= 200000 && a.M < (1 << 21)) return launch_wgrad2(g, x, dy, dw, st);
     if (dtype == YDL_F32) wgrad_kernel<float, false><<<grid, 256, 0, st>>>(a);
     else if (g_wgrad_tr) wgrad_kernel<bf16_t, true><<<grid, 256, 0, st>>>(a);
     else wgrad_kernel<bf16_t, false><<<grid, 256, 0, st>>>(a);
