@@ -1,7 +1,7 @@
 """Process-wide settings of the HIP path."""
 from __future__ import annotations
 
-_STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True}
+_STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True, "fuse_siblings": True}
 
 
 def set_compute_dtype(name: str) -> None:
@@ -23,6 +23,15 @@ def lazy_upsample() -> bool:
 
 def set_lazy_upsample(on: bool) -> None:
     _STATE["lazy_upsample"] = bool(on)
+
+
+def fuse_siblings() -> bool:
+    """cv1/cv2 of a CSP block run as one convolution when their parameters are adjacent in the flat arenas"""
+    return _STATE["fuse_siblings"]
+
+
+def set_fuse_siblings(on: bool) -> None:
+    _STATE["fuse_siblings"] = bool(on)
 
 
 def weight_epoch() -> int:

@@ -206,6 +206,10 @@ class Conv(YdlModule):
         wp = self.conv.weight
         return (tape.dname, wp.data_ptr(), wp._version, config.weight_epoch())
 
+    def mark_step(self, tape: Tape) -> None:
+        if tape.train:
+            self.bn._nbt_pending += 1
+
     def _wbuffers(self, tape: Tape, master: torch.Tensor):
         kk = self.k * self.k
         dev = master.device
@@ -264,13 +268,155 @@ class Conv(YdlModule):
     # -- forward ----------------------------------------------------------------------------------------
     def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None, res: Optional[Var] = None,
              res_mode: int = L.RES_NONE, act_code: Optional[int] = None) -> Var:
-        if tape.train:
-            self.bn._nbt_pending += 1
+        self.mark_step(tape)
         return tape.conv_bn_act(x, self, self.s, self.p, self.act_code if act_code is None else act_code,
                                 out=out, res=res, res_mode=res_mode)
 
     def forward_fuse(self, x):
         raise NotImplementedError("inference-time Conv+BN folding is out of scope (SURVEY §8f-2)")
+
+
+class _FusedPair:
+    """Two 1x1 Convs that read the SAME input (cv1/cv2 of a CSP block) run as ONE convolution with concatenated output
+    channels: the input is read once in forward and wgrad, and dgrad writes the input gradient once instead of
+    write + read-modify-write.  Possible without any copy when the two modules' parameters, gradients and BN buffers
+    are adjacent in memory — which is how yolo_dual_amd.optim.FlatSGDEMA lays the arenas out; otherwise ``make``
+    returns None and the block falls back to two convolutions.  Duck-types the part of ``Conv`` the tape uses."""
+
+    def __init__(self, a: "Conv", b: "Conv"):
+        self.a, self.b = a, b
+        self.c1, self.c2, self.k, self.s, self.p = a.c1, a.c2 + b.c2, a.k, a.s, a.p
+        self.act_code = a.act_code
+        self._wcache = {}
+        self._views = None
+
+    @staticmethod
+    def _adjacent(t1: torch.Tensor, t2: torch.Tensor) -> bool:
+        return (t1 is not None and t2 is not None and t1.dtype == t2.dtype and
+                t1.data_ptr() + t1.numel() * t1.element_size() == t2.data_ptr())
+
+    @classmethod
+    def make(cls, a: "Conv", b: "Conv") -> Optional["_FusedPair"]:
+        if (a.k, a.s, a.p, a.c1, a.act_code) != (b.k, b.s, b.p, b.c1, b.act_code) or a.k != 1:
+            return None
+        if a.c2 % 8 or b.c2 % 8:
+            return None
+        pairs = [(a.conv.weight, b.conv.weight), (a.bn.weight, b.bn.weight), (a.bn.bias, b.bn.bias),
+                 (a.bn.running_mean, b.bn.running_mean), (a.bn.running_var, b.bn.running_var)]
+        if not all(cls._adjacent(x.detach(), y.detach()) for x, y in pairs):
+            return None
+        if not (a.conv.weight.detach().permute(0, 2, 3, 1).is_contiguous() and
+                b.conv.weight.detach().permute(0, 2, 3, 1).is_contiguous()):
+            return None
+        return cls(a, b)
+
+    def still_valid(self) -> bool:
+        a, b = self.a, self.b
+        key = (a.conv.weight.data_ptr(), b.conv.weight.data_ptr(), a.bn.running_mean.data_ptr())
+        if self._views is not None and self._views[0] == key:
+            return True
+        if _FusedPair.make(a, b) is None:
+            return False
+        c = self.c2
+
+        def cat1(x, y):
+            return torch.as_strided(x.detach(), (c,), (1,))
+        w = torch.as_strided(a.conv.weight.detach().permute(0, 2, 3, 1), (c, self.k, self.k, self.c1),
+                             (self.k * self.k * self.c1, self.k * self.c1, self.c1, 1))
+        bn = _FusedBN()
+        bn.weight, bn.bias = cat1(a.bn.weight, b.bn.weight), cat1(a.bn.bias, b.bn.bias)
+        bn.running_mean, bn.running_var = cat1(a.bn.running_mean, b.bn.running_mean), cat1(a.bn.running_var, b.bn.running_var)
+        bn.eps, bn.momentum = a.bn.eps, a.bn.momentum
+        self._views = (key, w, bn)
+        return True
+
+    @property
+    def bn(self):
+        return self._views[2]
+
+    def _master_krsc(self) -> torch.Tensor:
+        return self._views[1]
+
+    def _wkey(self, tape: Tape):
+        wa, wb = self.a.conv.weight, self.b.conv.weight
+        return (tape.dname, wa.data_ptr(), wa._version, wb._version, config.weight_epoch())
+
+    _wbuffers = None        # bound below (shared implementation with Conv)
+    compute_weights = None
+    coeffs = None
+
+    def mark_step(self, tape: Tape) -> None:
+        self.a.mark_step(tape)
+        self.b.mark_step(tape)
+
+    def _grads(self, which: str):
+        if which == "w":
+            return self.a.conv.weight, self.b.conv.weight
+        return (self.a.bn.weight, self.b.bn.weight) if which == "gamma" else (self.a.bn.bias, self.b.bn.bias)
+
+    def grads_adjacent(self) -> bool:
+        for which in ("w", "gamma", "beta"):
+            p1, p2 = self._grads(which)
+            if p1.grad is None or p2.grad is None or not self._adjacent(p1.grad, p2.grad):
+                return False
+        g = self.a.conv.weight.grad
+        return g.permute(0, 2, 3, 1).is_contiguous() and self.b.conv.weight.grad.permute(0, 2, 3, 1).is_contiguous()
+
+    def grad_slot(self, tape: Tape, which: str):
+        p1, p2 = self._grads(which)
+        config.mark_touched(p1)
+        config.mark_touched(p2)
+        return torch.as_strided(p1.grad, (self.c2,), (1,)), 1
+
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
+        p1, p2 = self._grads("w")
+        gk = p1.grad.permute(0, 2, 3, 1)
+        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(gk), st)
+        config.mark_touched(p1)
+        config.mark_touched(p2)
+
+
+class _FusedBN:
+    pass
+
+
+_FusedPair._wbuffers = Conv._wbuffers
+_FusedPair.compute_weights = Conv.compute_weights
+_FusedPair.coeffs = Conv.coeffs
+
+
+def _csp_forward(blk, tape: Tape, x: Var, add: bool) -> Var:
+    """shared by C3 / C3Common / C3k2: cv3(cat(m(cv1 x), cv2 x)) (+x) with cv1|cv2 fused when the memory layout allows.
+    Buffer T has 3*c_ channels [a | m_out | right]: the fused conv's two halves are activated into T[0:c_] and
+    T[2c_:3c_], the last layer of ``m`` writes T[c_:2c_], and cv3 reads the contiguous slice T[c_:3c_] (no copy)."""
+    c_, n = blk.c_, len(blk.m)
+    pair = getattr(blk, "_pair", None)
+    if pair is None:
+        pair = blk._pair = _FusedPair(blk.cv1, blk.cv2)
+    fused = (config.fuse_siblings() and x.aligned() and not x.lazy and pair.still_valid() and
+             (not tape.record or pair.grads_adjacent()))
+    if not fused:
+        cat = tape.new(x.N, 2 * c_, x.H, x.W)
+        left, right = cat.slice(0, c_), cat.slice(c_, 2 * c_)
+        a = blk.cv1._fwd(tape, x, out=left if n == 0 else None)
+        for i, mm in enumerate(blk.m):
+            a = mm._fwd(tape, a, out=left if i == n - 1 else None)
+        blk.cv2._fwd(tape, x, out=right)
+    else:
+        pair.mark_step(tape)
+        if n == 0:
+            cat = tape.conv_bn_act(x, pair, pair.s, pair.p, pair.act_code)
+        else:
+            T = tape.new(x.N, 3 * c_, x.H, x.W)
+            cat = T.slice(c_, 3 * c_)                 # what cv3 reads: [m_out | right]
+            a = T.slice(0, c_)
+            mslot, right = cat.slice(0, c_), cat.slice(c_, 2 * c_)   # nested slices: they see cat's gradient state
+            tape.conv_bn_act(x, pair, pair.s, pair.p, pair.act_code, out=[a, right])
+            for i, mm in enumerate(blk.m):
+                a = mm._fwd(tape, a, out=mslot if i == n - 1 else None)
+    if add:
+        return blk.cv3._fwd(tape, cat, res=x, res_mode=L.RES_AFTER_ACT)
+    return blk.cv3._fwd(tape, cat)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -290,17 +436,7 @@ class C3(YdlModule):
         self.c_ = c_
 
     def _fwd(self, tape: Tape, x: Var) -> Var:
-        c_ = self.c_
-        cat = tape.new(x.N, 2 * c_, x.H, x.W)
-        left, right = cat.slice(0, c_), cat.slice(c_, 2 * c_)
-        n = len(self.m)
-        a = self.cv1._fwd(tape, x, out=left if n == 0 else None)
-        for i, mm in enumerate(self.m):
-            a = mm._fwd(tape, a, out=left if i == n - 1 else None)
-        self.cv2._fwd(tape, x, out=right)
-        if self.add:
-            return self.cv3._fwd(tape, cat, res=x, res_mode=L.RES_AFTER_ACT)
-        return self.cv3._fwd(tape, cat)
+        return _csp_forward(self, tape, x, self.add)
 
 
 class C3k2(C3):
@@ -338,15 +474,7 @@ class C3Common(YdlModule):
         self.c_ = c_
 
     def _fwd(self, tape: Tape, x: Var) -> Var:
-        c_ = self.c_
-        cat = tape.new(x.N, 2 * c_, x.H, x.W)
-        left, right = cat.slice(0, c_), cat.slice(c_, 2 * c_)
-        n = len(self.m)
-        a = self.cv1._fwd(tape, x, out=left if n == 0 else None)
-        for i, mm in enumerate(self.m):
-            a = mm._fwd(tape, a, out=left if i == n - 1 else None)
-        self.cv2._fwd(tape, x, out=right)
-        return self.cv3._fwd(tape, cat)
+        return _csp_forward(self, tape, x, False)
 
 
 class C2f(YdlModule):

@@ -45,7 +45,11 @@ class FlatSGDEMA(torch.optim.Optimizer):
                     g1.append(p)
                 else:
                     g0.append(p)
-        bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
+        # float buffers, all running means first, then all running variances (module order inside each): sibling
+        # convolutions keep adjacent statistics, which lets CSP blocks run cv1|cv2 as one fused conv
+        named = [(k, b) for k, b in model.named_buffers() if b.dtype.is_floating_point]
+        bufs = ([b for k, b in named if k.endswith("running_mean")] + [b for k, b in named if k.endswith("running_var")] +
+                [b for k, b in named if not (k.endswith("running_mean") or k.endswith("running_var"))])
         self.model = model
         self._groups3 = (g0, g1, g2)
         self._bufs = bufs

@@ -206,14 +206,17 @@ class Tape:
         self.bw.clear()
 
     # ------------------------------------------------------------------ conv + BN + act (+ residual)
-    def conv_bn_act(self, x: Var, m, s: int, p: int, act: int, out: Optional[Var] = None,
+    def conv_bn_act(self, x: Var, m, s: int, p: int, act: int, out=None,
                     res: Optional[Var] = None, res_mode: int = L.RES_NONE) -> Var:
-        """out = act(bn(conv(x))) [+ res].  ``m`` is a yolo_dual_amd.modules.Conv (parameter holder).
+        """out = act(bn(conv(x))) [+ res].  ``m`` is a yolo_dual_amd.modules.Conv (parameter holder) or a fused sibling
+        pair.  ``out`` may be a Var (typically a concat slice) or a LIST of Vars that split the output channels (fused
+        siblings: each part is activated into its own destination).
         Reference: Conv.forward seg_diceloss_yolov5.py:403-409."""
         k = m.k
         Cout, Cin = m.c2, m.c1
         if x.C != Cin:
             raise RuntimeError(f"Conv layer input channel mismatch: got {x.C}, weight expects {Cin}")
+        outs = list(out) if isinstance(out, (list, tuple)) else None
         rep = 1
         if x.lazy:
             if k == 1 and s == 1 and p == 0 and res is None and out is None:
@@ -226,71 +229,92 @@ class Tape:
             x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need))
         if res is not None and not res.aligned():
             res = self.copy(res, self.new(res.N, res.C, res.H, res.W, need=res.need))
-        if out is not None and not out.aligned():
+        if outs is None and out is not None and not out.aligned():
             tmp = self.conv_bn_act(x, m, s, p, act, None, res, res_mode)
             return self.copy(tmp, out)
         Ho = (x.H + 2 * p - k) // s + 1
         Wo = (x.W + 2 * p - k) // s + 1
         y = self.new(x.N, Cout, Ho, Wo)
-        if out is None:
-            out = self.new(x.N, Cout, Ho, Wo)
-            out.rep = x.rep
-        elif (out.N, out.C, out.H, out.W) != (x.N, Cout, Ho, Wo):
-            raise RuntimeError("conv_bn_act: output slice has the wrong shape")
+        if outs is None:
+            if out is None:
+                out = self.new(x.N, Cout, Ho, Wo)
+                out.rep = x.rep
+            elif (out.N, out.C, out.H, out.W) != (x.N, Cout, Ho, Wo):
+                raise RuntimeError("conv_bn_act: output slice has the wrong shape")
+            outs = [out]
+        else:
+            if sum(o.C for o in outs) != Cout or any(o.C % 8 or not o.aligned() for o in outs) or res is not None:
+                raise RuntimeError("conv_bn_act: split outputs must be aligned channel groups summing to Cout")
+        parts = []                                 # (channel offset, width, destination Var)
+        c0 = 0
+        for o in outs:
+            parts.append((c0, o.C, o))
+            c0 += o.C
         geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld)
         gp = ctypes.byref(geom)
         st = _stream()
         w, wt = m.compute_weights(self)
-        Cp = round_up(Cout, 8)
+        npix = x.N * Ho * Wo
         cf = m.coeffs(self.device)                   # dict of f32 [Cp] tensors: mean, invstd, scale, shift
         if self.train:
             nbytes = L.lib().ydl_conv_fwd_stats_ws_bytes(gp, self.dt)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
             L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), _p(ws), st)
             L.call("ydl_bn_finalize", _p(ws), L.lib().ydl_conv_fwd_grid_m(gp), L.lib().ydl_conv_fwd_block_m(gp),
-                   x.N * Ho * Wo, Cout, _p(m.bn.weight), _p(m.bn.bias), m.bn.eps, m.bn.momentum,
+                   npix, Cout, _p(m.bn.weight), _p(m.bn.bias), m.bn.eps, m.bn.momentum,
                    _p(m.bn.running_mean), _p(m.bn.running_var), _p(cf["mean"]), _p(cf["invstd"]),
                    _p(cf["scale"]), _p(cf["shift"]), rep, st)
         else:
             L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), None, st)
             L.call("ydl_bn_eval_coeffs", Cout, _p(m.bn.weight), _p(m.bn.bias), _p(m.bn.running_mean),
                    _p(m.bn.running_var), m.bn.eps, _p(cf["scale"]), _p(cf["shift"]), st)
-        L.call("ydl_bn_act_fwd", self.dt, _p(y.t), y.ld, _p(cf["scale"]), _p(cf["shift"]),
-               _p(res.t) if res is not None else None, res.ld if res is not None else 0, res_mode, act,
-               _p(out.t), out.ld, x.N * Ho * Wo, Cp, st)
+        single = len(parts) == 1
+        for (co, cw, o) in parts:
+            cp = round_up(cw, 8)
+            L.call("ydl_bn_act_fwd", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld,
+                   _p(cf["scale"][co:]), _p(cf["shift"][co:]),
+                   _p(res.t) if res is not None else None, res.ld if res is not None else 0, res_mode, act,
+                   _p(o.t), o.ld, npix, cp, st)
+        ret = outs[0] if single else None
         if not self.record:
-            return out
+            return ret
         if not self.train:
             raise RuntimeError("backward through eval-mode BatchNorm is not supported")
 
         def bw():
-            if not out.is_set():
+            if not any(o.is_set() for (_c, _w, o) in parts):
                 return                                   # dead branch: parameters keep grad None
-            dout = self._gbuf(out)
             st2 = _stream()
             dy = self.new(x.N, Cout, Ho, Wo)
-            dres_t, dres_ld, tmp_dres = None, 0, None
-            if res is not None and res.need and res_mode == L.RES_BEFORE_ACT:
-                if res.is_set():
-                    tmp_dres = self.new_like(res)
-                    dres_t, dres_ld = tmp_dres.t, tmp_dres.ld
-                else:
-                    gbuf, _ = self.grad_target(res)
-                    dres_t, dres_ld = gbuf, res.ld
-            nws = L.lib().ydl_bn_bwd_ws_bytes(out.npix, Cp) // 4
-            ws2 = torch.empty(nws, dtype=torch.float32, device=self.device)
             gw, accw = m.grad_slot(self, "gamma")
             gb, _ = m.grad_slot(self, "beta")
-            L.call("ydl_bn_act_bwd", self.dt, _p(y.t), y.ld, _p(dout), out.ld, _p(out.t), out.ld,
-                   _p(m.bn.weight), _p(cf["mean"]), _p(cf["invstd"]), _p(cf["scale"]), _p(cf["shift"]),
-                   res_mode, act, _p(dy.t), dy.ld, _p(dres_t), dres_ld, _p(gw), _p(gb), accw,
-                   _p(ws2), out.npix, Cout, Cp, st2)
-            if tmp_dres is not None:
-                gbuf, acc = self.grad_target(res)
-                L.call("ydl_copy2d", self.dt, _p(tmp_dres.t), tmp_dres.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
-            if res is not None and res.need and res_mode == L.RES_AFTER_ACT:
-                gbuf, acc = self.grad_target(res)
-                L.call("ydl_copy2d", self.dt, _p(dout), out.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
+            for (co, cw, o) in parts:
+                cp = round_up(cw, 8)
+                dyv = dy.t if single else dy.t[:, co:co + cw]
+                if not o.is_set():                        # this half feeds nothing that reaches the loss
+                    dyv.zero_()
+                    continue
+                dout = self._gbuf(o)
+                dres_t, dres_ld, tmp_dres = None, 0, None
+                if res is not None and res.need and res_mode == L.RES_BEFORE_ACT:
+                    if res.is_set():
+                        tmp_dres = self.new_like(res)
+                        dres_t, dres_ld = tmp_dres.t, tmp_dres.ld
+                    else:
+                        gbuf, _ = self.grad_target(res)
+                        dres_t, dres_ld = gbuf, res.ld
+                nws = L.lib().ydl_bn_bwd_ws_bytes(npix, cp) // 4
+                ws2 = torch.empty(nws, dtype=torch.float32, device=self.device)
+                L.call("ydl_bn_act_bwd", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld, _p(dout), o.ld,
+                       _p(o.t), o.ld, _p(m.bn.weight[co:]), _p(cf["mean"][co:]), _p(cf["invstd"][co:]),
+                       _p(cf["scale"][co:]), _p(cf["shift"][co:]), res_mode, act, _p(dyv), dy.ld, _p(dres_t), dres_ld,
+                       _p(gw[co:]), _p(gb[co:]), accw, _p(ws2), npix, cw, cp, st2)
+                if tmp_dres is not None:
+                    gbuf, acc = self.grad_target(res)
+                    L.call("ydl_copy2d", self.dt, _p(tmp_dres.t), tmp_dres.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
+                if res is not None and res.need and res_mode == L.RES_AFTER_ACT:
+                    gbuf, acc = self.grad_target(res)
+                    L.call("ydl_copy2d", self.dt, _p(dout), o.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
             # weight gradient (f32, KRSC) accumulated into the parameter's grad storage
             m.wgrad(self, gp, x, dy, st2)
             if x.need:
@@ -299,7 +323,7 @@ class Tape:
             _keep = (geom,)   # keep the ctypes struct alive for the closure
 
         self.bw.append(bw)
-        return out
+        return ret
 
     # ------------------------------------------------------------------ pooling / resize / copies
     def maxpool(self, x: Var, k: int, s: int, p: int, out: Optional[Var] = None) -> Var:
