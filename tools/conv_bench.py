@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--nostats", action="store_true")
     a = ap.parse_args()
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -51,7 +52,7 @@ def main():
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         flops = 2.0 * N * Ho * Ho * Cout * k * k * Cin
         byts = (N * Hi * Hi * Cin + N * Ho * Ho * Cout) * (2 if a.dtype == "bf16" else 4)
-        ops = {"fwd": lambda: L.call("ydl_conv_fwd", gp, dt, P(x), P(w), P(y), P(ws), st),
+        ops = {"fwd": lambda: L.call("ydl_conv_fwd", gp, dt, P(x), P(w), P(y), None if a.nostats else P(ws), st),
                "dgrad": lambda: L.call("ydl_conv_dgrad", gp, dt, P(dy), P(wt), P(dx), 0, st),
                "wgrad": lambda: L.call("ydl_conv_wgrad", gp, dt, P(x), P(dy), P(dw), st)}
         line = f"[{li:2d}] {Cin:5d}->{Cout:5d} k{k}s{s} @{Ho:4d}"

@@ -56,6 +56,32 @@ template <> struct Mma<float> {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Sum NV per-lane values over the 16 lanes of a row (lanes 16g..16g+15).  Stages with more than one live value use
+// the transposing butterfly: the lane whose bit s is 0 keeps the even-indexed values, its partner the odd ones, each
+// adds the partner's copy => the live count halves and one shuffle serves two values.  Result: slot tt of lane r
+// holds the total of value index (tt << 4 | r) when NV >= 16, or of (r & (NV-1)) in slot 0 otherwise.
+template <int NV>
+__device__ __forceinline__ void row_reduce(float (&v)[NV], int lrow) {
+    int cnt = NV;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int mask = 1 << s;
+        const bool hi = (lrow >> s) & 1;
+        if (cnt > 1) {
+#pragma unroll
+            for (int i = 0; i < NV / 2; ++i)
+                if (i < cnt / 2) {
+                    float a = v[2 * i], b = v[2 * i + 1];
+                    float keep = hi ? b : a, send = hi ? a : b;
+                    v[i] = keep + __shfl_xor(send, mask, 64);
+                }
+            cnt >>= 1;
+        } else {
+            v[0] += __shfl_xor(v[0], mask, 64);
+        }
+    }
+}
+
 // BM = pixel tile (64 or 128), BN = output-channel tile (16, 64 or 128).  256 threads = 4 waves, each wave
 // owns BM/4 pixels x all BN channels.
 //
@@ -257,26 +283,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
 
     // ---------------- epilogue: BN partial statistics (block-local two-pass => Chan-mergeable) ----------
+    // A lane holds NV = 4*CT channel values per pixel; the sum over the 16 pixel-lanes of a row is a transposing
+    // butterfly (each stage halves the values a lane keeps): 30 shuffles for 32 values instead of 128.
     if (p.stats != nullptr) {
+        constexpr int NV = 4 * CT;
         float* red = (float*)smem;             // [4][BN]; safe: all LDS reads finished at the last barrier
         float* smean = red + 4 * BN;           // [BN]
         const int nvalid = min(BM, p.M - m0);
-        float s[CT][4];
+        const int lgrp = lane >> 4;
+        float v[NV];
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = 0.f;
+                float t2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < PT; ++j) v += acc[c][j][e];   // rows beyond M are exact zeros
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                s[c][e] = v;
+                for (int j = 0; j < PT; ++j) t2 += acc[c][j][e];   // rows beyond M are exact zeros
+                v[c * 4 + e] = t2;
             }
-        if (lrow == 0) {
+        row_reduce<NV>(v, lrow);
+        // after the reduce, slot tt of lane lrow holds value index (tt << 4 | lrow) (NV >= 16) or (lrow & (NV-1))
+        auto chan_of = [&](int idx) { return (idx >> 2) * 16 + lgrp * 4 + (idx & 3); };
+        if (NV >= 16) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) red[wave * BN + c * 16 + cq + e] = s[c][e];
+            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wave * BN + chan_of((tt << 4) | lrow)] = v[tt];
+        } else if (lrow < NV) {
+            red[wave * BN + chan_of(lrow)] = v[0];
         }
         __syncthreads();
         float tot = 0.f;
@@ -290,22 +322,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float mu = smean[c * 16 + cq + e];
-                float v = 0.f;
+                float t2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < PT; ++j) {
                     int m = m0 + wave * (BM / 4) + j * 16 + lrow;
                     float d = acc[c][j][e] - mu;
-                    v += (m < p.M) ? d * d : 0.f;
+                    t2 += (m < p.M) ? d * d : 0.f;
                 }
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                s[c][e] = v;
+                v[c * 4 + e] = t2;
             }
+        row_reduce<NV>(v, lrow);
         __syncthreads();   // everyone has read smean/red before red is overwritten
-        if (lrow == 0) {
+        if (NV >= 16) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) red[wave * BN + c * 16 + cq + e] = s[c][e];
+            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wave * BN + chan_of((tt << 4) | lrow)] = v[tt];
+        } else if (lrow < NV) {
+            red[wave * BN + chan_of(lrow)] = v[0];
         }
         __syncthreads();
         if (t < BN && n0 + t < p.Cout) {
