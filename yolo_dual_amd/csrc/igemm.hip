@@ -11,6 +11,7 @@
 // bf16: v_mfma_f32_16x16x32_bf16, lane reads 8 consecutive k.  f32: 4 x v_mfma_f32_16x16x4_f32 on the 4
 // floats of the same 16-byte read (k permuted identically for both operands; exact f32 fmaf chains).
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef YDL_PF
 #define YDL_PF 1     // deeper register prefetch costs an occupancy step on the 128x128 tile (measured slower)
@@ -524,7 +525,13 @@ struct WgradArgs {
     int M;                        // N*Ho*Wo
     int chunk;                    // pixels per split (multiple of 64)
     int ntaps;
+    unsigned long long magicW, magicHW;   // ceil(2^40 / Wo), ceil(2^40 / (Ho*Wo)): division-free pixel decode
+    unsigned bytesX, bytesY;
 };
+
+__device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
+    return (unsigned)(((unsigned long long)n * magic) >> 40);
+}
 
 #define WG_BKP 64
 
@@ -562,25 +569,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int HoWo = p.Ho * p.Wo;
-    for (int p0 = pbeg; p0 < pend; p0 += WG_BKP) {
-        uint4 vy[2], vx[2];
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.bytesX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, p.bytesY, 0x00020000);
+    uint4 vy[2], vx[2];
+    // range-checked buffer loads (zeros for padding taps / tail rows), multiply-shift pixel decode
+    auto gload = [&](int p0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int m = p0 + r + 32 * i;
-            vy[i] = make_uint4(0, 0, 0, 0);
-            vx[i] = make_uint4(0, 0, 0, 0);
-            if (m < pend) {
-                if (yv) vy[i] = *(const uint4*)(Yg + (size_t)m * p.ldy + co_chunk);
-                if (qv) {
-                    int n = m / HoWo;
-                    int rem = m - n * HoWo;
-                    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    int ih = ho * p.s + dh, iw = wo * p.s + dw;
-                    if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-                        vx[i] = *(const uint4*)(Xg + ((size_t)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc);
-                }
-            }
+            bool in = m < pend;
+            unsigned offy = (in && yv) ? (unsigned)(m * p.ldy + co_chunk) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
+            u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsY, offy, 0, 0);
+            vy[i] = make_uint4(a.x, a.y, a.z, a.w);
+            unsigned n = fastdiv40((unsigned)m, p.magicHW);
+            unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+            unsigned ho = fastdiv40(rem, p.magicW);
+            unsigned wo = rem - ho * (unsigned)p.Wo;
+            int ih = (int)ho * p.s + dh, iw = (int)wo * p.s + dw;
+            bool ok = in && qv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            unsigned offx = ok ? (unsigned)(((int)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
+            u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsX, offx, 0, 0);
+            vx[i] = make_uint4(b.x, b.y, b.z, b.w);
         }
+    };
+    gload(pbeg);
+    for (int p0 = pbeg; p0 < pend; p0 += WG_BKP) {
         __syncthreads();   // previous stage's LDS reads done
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -588,6 +601,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             *(uint4*)(sX + (r + 32 * i) * ROWB + q * 16) = vx[i];
         }
         __syncthreads();
+        if (p0 + WG_BKP < pend) gload(p0 + WG_BKP);      // next stage in flight while this one is multiplied
         if constexpr (sizeof(T) == 2 && !TR) {
             const int g = lane >> 4, li = lane & 15;
 #pragma unroll
@@ -688,10 +702,6 @@ struct Wgrad2Args {
     unsigned long long magicW, magicHW;   // ceil(2^40 / Wo), ceil(2^40 / (Ho*Wo))
     unsigned bytesX, bytesY;
 };
-
-__device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
-    return (unsigned)(((unsigned long long)n * magic) >> 40);
-}
 
 template <int TCO>
 __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
@@ -874,13 +884,27 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
     a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = g->k * g->k;
     a.M = g->N * g->Ho * g->Wo;
+    {
+        unsigned long long es = (unsigned long long)esize(dtype);
+        unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * es, by = (unsigned long long)a.M * g->ldy * es;
+        YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M < (1ull << 21),
+                  "tensor too large for the 32-bit wgrad addressing");
+        a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by;
+        a.magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
+        a.magicHW = ((1ull << 40) + (unsigned long long)g->Ho * g->Wo - 1) / ((unsigned long long)g->Ho * g->Wo);
+    }
     const int TE = dtype == YDL_F32 ? 32 : 64;
     int jtiles = (a.ntaps * a.Kc + TE - 1) / TE;
     int ctiles = (g->Cout + TE - 1) / TE;
-    // split pixels so that the grid has ~2048 blocks, each with at least 4 stages
+    // split-K over pixels.  Every split adds one f32 atomic pass over the dW tile (chip-wide atomic rate ~1.3 TB/s),
+    // so splits are bounded by an atomic-byte budget as well as by the CTA target (env knobs for tuning runs)
     long tiles = (long)jtiles * ctiles;
     int stages = (a.M + WG_BKP - 1) / WG_BKP;
-    int splits = (int)((2048 + tiles - 1) / tiles);
+    static const long target_ctas = getenv("YDL_WG_CTAS") ? atol(getenv("YDL_WG_CTAS")) : 2048;
+    static const long atomic_budget = getenv("YDL_WG_ATOMIC_MB") ? atol(getenv("YDL_WG_ATOMIC_MB")) * (1l << 20) : (1l << 40);
+    int splits = (int)((target_ctas + tiles - 1) / tiles);
+    long dw_bytes = (long)g->Cout * a.ntaps * a.Kc * 4;
+    if ((long)splits * dw_bytes > atomic_budget) splits = (int)(atomic_budget / dw_bytes);
     if (splits > stages / 4) splits = stages / 4;
     if (splits < 1) splits = 1;
     if (splits > 1024) splits = 1024;
