@@ -26,7 +26,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--nostats", action="store_true")
+    ap.add_argument("--wg", type=int, default=1)
     a = ap.parse_args()
+    L.lib().ydl_debug_set(0, a.wg)
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")

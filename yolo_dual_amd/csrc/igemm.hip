@@ -36,6 +36,7 @@ struct IgemmArgs {
     int M;            // N*Hg*Wg
     int stats_ld;
     unsigned bytesA, bytesB;   // buffer extents for the range-checked loads
+    int grid_n;                // number of output-channel tiles (the grid is 1-D: grid_m * grid_n)
     signed char dh[MAXTAPS], dw[MAXTAPS];
     unsigned char wt[MAXTAPS];
 };
@@ -56,6 +57,16 @@ template <> struct Mma<float> {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// XCD-aware work-item order (speed only, any placement is correct): the dispatcher deals consecutive workgroups
+// round-robin over the 8 XCDs, each with a private L2.  Remapping linear id L -> (L % 8) * chunk + L / 8 hands every XCD
+// a CONTIGUOUS range of logical tiles, so tiles that share operand panels (all N-tiles of one pixel tile, the halo
+// neighbours of a 3x3 conv, all weight-gradient tiles of one pixel range) hit the same L2 at about the same time.
+__device__ __forceinline__ int xcd_remap(int L, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = L & 7, slot = L >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
 // Sum NV per-lane values over the 16 lanes of a row (lanes 16g..16g+15).  Stages with more than one live value use
 // the transposing butterfly: the lane whose bit s is 0 keeps the even-indexed values, its partner the odd ones, each
@@ -107,8 +118,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = tile / p.grid_n, ntile = tile - mtile * p.grid_n;     // N-tiles of one pixel tile are neighbours
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
 
     if (t < MAXTAPS) {
         int da = 0, db = 0, dd = 0;
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         __syncthreads();
         if (t < BN && n0 + t < p.Cout) {
             float m2 = red[t] + red[BN + t] + red[2 * BN + t] + red[3 * BN + t];
-            float* dst = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld;
+            float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
             dst[n0 + t] = tot;
             dst[p.stats_ld + n0 + t] = m2;
         }
@@ -354,8 +367,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 // host side
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN>
-static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
-    dim3 grid((a.M + BM - 1) / BM, (a.Cst + BN - 1) / BN);
+static int launch_igemm(IgemmArgs a, hipStream_t st) {
+    a.grid_n = (a.Cst + BN - 1) / BN;
+    dim3 grid(((a.M + BM - 1) / BM) * a.grid_n);
     size_t smem = 2 * (BM + BN) * ROWB + 3 * MAXTAPS * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
@@ -527,6 +541,7 @@ struct WgradArgs {
     int ntaps;
     unsigned long long magicW, magicHW;   // ceil(2^40 / Wo), ceil(2^40 / (Ho*Wo)): division-free pixel decode
     unsigned bytesX, bytesY;
+    int njt, nct;                 // tile counts (1-D grid = njt * nct * splits)
 };
 
 __device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
@@ -544,7 +559,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char sX[WG_BKP * ROWB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wi = wave >> 1, wj = wave & 1;   // wave grid over (cout, j)
-    const int jt = blockIdx.x, ct = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);      // all tiles of one pixel range share an XCD's L2
+    const int jt = tile % p.njt, ct = (tile / p.njt) % p.nct, zt = tile / (p.njt * p.nct);
     const int q = t & 7, r = t >> 3;
     const int cpt = p.Kc / V;
     const int nchunks = p.ntaps * cpt;
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const bool yv = co_chunk < p.Cout;             // Cout % V may be != 0: tail handled by ldy padding zeros
     const T* Xg = (const T*)p.X;
     const T* Yg = (const T*)p.dY;
-    const int pbeg = blockIdx.z * p.chunk;
+    const int pbeg = zt * p.chunk;
     const int pend = min(p.M, pbeg + p.chunk);
 
     constexpr int NT = (sizeof(T) == 2) ? 2 : 1;   // 16x16 tiles per wave per dim
@@ -701,6 +717,7 @@ struct Wgrad2Args {
     int M, chunk, ntaps;
     unsigned long long magicW, magicHW;   // ceil(2^40 / Wo), ceil(2^40 / (Ho*Wo))
     unsigned bytesX, bytesY;
+    int njt, nct;
 };
 
 template <int TCO>
@@ -717,7 +734,8 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
     unsigned char* sX = smem + 2 * 64 * W2_ROWB;           // [2][64][W2_ROWB]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wi = wave / WJ, wj = wave % WJ;
-    const int jt = blockIdx.x, ct = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = tile % p.njt, ct = (tile / p.njt) % p.nct, zt = tile / (p.njt * p.nct);
     const int cpt = p.Kc / 8;
     const int nchunks = p.ntaps * cpt;
     // X tile: 16 chunks per row, 16 rows per pass, 4 passes;  this thread's chunk (=> tap, channel) is fixed
@@ -731,7 +749,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
     const int yq = t % YCH, yr = t / YCH;
     const int co_chunk = ct * TCO + yq * 8;
     const bool yv = co_chunk < p.Cout;
-    const int pbeg = blockIdx.z * p.chunk;
+    const int pbeg = zt * p.chunk;
     const int pend = min(p.M, pbeg + p.chunk);
     const int HoWo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.bytesX, 0x00020000);
@@ -855,7 +873,8 @@ static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, 
     int per = (stages + splits - 1) / splits;
     a.chunk = per * 64;
     splits = (a.M + a.chunk - 1) / a.chunk;
-    dim3 grid(jtiles, ctiles, splits);
+    a.njt = jtiles; a.nct = ctiles;
+    dim3 grid(jtiles * ctiles * splits);
     size_t smem = 4 * 64 * W2_ROWB;
     static bool attr_set = false;
     if (!attr_set) {
@@ -911,7 +930,8 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     int per = (stages + splits - 1) / splits;
     a.chunk = per * WG_BKP;
     splits = (a.M + a.chunk - 1) / a.chunk;
-    dim3 grid(jtiles, ctiles, splits);
+    a.njt = jtiles; a.nct = ctiles;
+    dim3 grid(jtiles * ctiles * splits);
     hipStream_t st = (hipStream_t)stream;
     // measured on MI355X: the 128-wide pipelined kernel wins on the large-M layers (>= 160x160 at bs 16), the small
     // 64x64-tile kernel (8 CTAs/CU) wins where M is small and the grid of big tiles would be latency-bound
