@@ -131,6 +131,18 @@ int ydl_nhwc_to_nchw(int dtype, const void* src, int lds, float* dst, int N, int
 int ydl_scale_channels(int dtype, const void* x, int ldx, const float* gate /*[N][C]*/, void* y, int ldy,
                        int N, int64_t hw, int C, void* stream);
 
+/* GAM (unet-lite/yolo9-seg/seg_diceloss_yolov9.py:475-510): global average / max pooling to 1x1 (argmax = pixel index of the
+ * first maximum, int32 [N][round_up(C,8)]), sigmoid gate of two pooled branches, per-(n,c) dot product */
+int ydl_global_pool_fwd(int dtype, const void* x, int ldx, void* avg, int lda, void* mx, int ldm, int32_t* argmax,
+                        int N, int64_t HW, int C, void* stream);
+int ydl_global_pool_bwd(int dtype, const void* davg, int lda, const void* dmx, int ldm, const int32_t* argmax,
+                        void* dx, int lddx, int accumulate, int N, int64_t HW, int C, void* stream);
+int ydl_gate_fwd(int dtype, const void* a, int lda, const void* b, int ldb, float* gate, int N, int C, void* stream);
+int ydl_gate_bwd(int dtype, const float* gate, const float* dgate, void* da, int lda, int acc_a, void* db, int ldb,
+                 int acc_b, int N, int C, void* stream);
+int ydl_channel_dot(int dtype, const void* a, int lda, const void* b, int ldb, float* out, int N, int64_t HW, int C,
+                    void* stream);
+
 /* ---- softmax over channels (the yaml models end in nn.Softmax(1)) ----------------------------------- */
 /* x: NHWC compute dtype (C<=32), stored at (H, W); p: f32 of logical size (N, C, H*rep_h, W*rep_w) with element
  * strides (sn, sc, sh, sw) — NCHW or NHWC.  rep_* > 1 fuses a nearest up-sampling of the probabilities. */

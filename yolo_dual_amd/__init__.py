@@ -8,7 +8,7 @@ from .config import compute_dtype, set_compute_dtype
 from .loss import JaccardSegmentationLoss, SegmentationLoss
 from .models import (ResNet18, ResNet18Seg, ResNet50, ResNet50Seg, SegYoloModel, YOLOv5Seg, YOLOv8Seg, YOLOv9Seg,
                      parse_model)
-from .modules import (C2f, C3, C3k2, BasicBlock, Bottleneck, BottleneckBlock, C3Common, Concat, Conv, MaxPool2d,
+from .modules import (GAM, C2f, C3, C3k2, BasicBlock, Bottleneck, BottleneckBlock, C3Common, Concat, Conv, MaxPool2d,
                       SegmentHead, SPPF, Upsample, autopad)
 from .optim import FlatSGDEMA, smart_optimizer
 

@@ -53,6 +53,11 @@ SIGNATURES = {
     "ydl_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ydl_nhwc_to_nchw": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ydl_scale_channels": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i64, _i, _vp]),
+    "ydl_global_pool_fwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    "ydl_global_pool_bwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _i, _vp]),
+    "ydl_gate_fwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "ydl_gate_bwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "ydl_channel_dot": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "ydl_softmax_fwd": (_i, [_i, _vp, _i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "ydl_softmax_bwd": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ydl_seg_loss_ws_floats": (_i64, [_i, _i]),

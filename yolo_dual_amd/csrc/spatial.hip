@@ -421,3 +421,181 @@ extern "C" int ydl_scale_channels(int dtype, const void* x, int ldx, const float
     YDL_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------
+// GAM support (unet-lite/yolo9-seg/seg_diceloss_yolov9.py:475-510): global avg / max pooling to 1x1, the sigmoid
+// gate, per-(n,c) dot product for the gate gradient.  One CTA per (image, 16-byte channel chunk).
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void global_pool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ avg, int lda,
+                                                              T* __restrict__ mx, int ldm, int* __restrict__ amax,
+                                                              long long HW, int Cp) {
+    constexpr int V = ET<T>::V;
+    const int n = blockIdx.y, c = blockIdx.x * V;
+    const T* xb = x + (size_t)n * HW * ldx + c;
+    float s[V], m[V];
+    int mi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s[e] = 0.f; m[e] = -INFINITY; mi[e] = 0; }
+    for (long long p = threadIdx.x; p < HW; p += 256) {
+        float v[V];
+        unpack16<T>(*(const uint4*)(xb + p * ldx), v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            s[e] += v[e];
+            if (v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; mi[e] = (int)p; }
+        }
+    }
+    __shared__ float ss[256][8], sm[256][8];
+    __shared__ int si[256][8];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { ss[threadIdx.x][e] = s[e]; sm[threadIdx.x][e] = m[e]; si[threadIdx.x][e] = mi[e]; }
+    __syncthreads();
+    if (threadIdx.x < V) {
+        const int e = threadIdx.x;
+        float a = 0.f, b = -INFINITY;
+        int bi = 0;
+        for (int t = 0; t < 256; ++t) {
+            a += ss[t][e];
+            float v = sm[t][e];
+            int vi = si[t][e];
+            // first maximum in scan order (ATen adaptive_max_pool semantics): larger value, or equal value at lower index
+            if (v > b || (v == b && vi < bi)) { b = v; bi = vi; }
+        }
+        ET<T>::st(avg + (size_t)n * lda + c + e, a / (float)HW);
+        ET<T>::st(mx + (size_t)n * ldm + c + e, b);
+        amax[(size_t)n * Cp + c + e] = bi;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void global_pool_bwd_kernel(const T* __restrict__ davg, int lda, const T* __restrict__ dmx, int ldm,
+                                                              const int* __restrict__ amax, T* __restrict__ dx, int lddx,
+                                                              int accumulate, int N, long long HW, int Cp) {
+    constexpr int V = ET<T>::V;
+    const int cpp = Cp / V;
+    const long long total = (long long)N * HW * cpp;
+    const float inv = 1.f / (float)HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int cq = (int)(i % cpp);
+        long long pix = i / cpp;
+        int n = (int)(pix / HW);
+        int p = (int)(pix - (long long)n * HW);
+        int c = cq * V;
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = 0.f;
+        if (accumulate) unpack16<T>(*(const uint4*)(dx + pix * lddx + c), g);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (davg) g[e] += ET<T>::ld(davg + (size_t)n * lda + c + e) * inv;
+            if (dmx && amax[(size_t)n * Cp + c + e] == p) g[e] += ET<T>::ld(dmx + (size_t)n * ldm + c + e);
+        }
+        *(uint4*)(dx + pix * lddx + c) = pack16<T>(g);
+    }
+}
+extern "C" int ydl_global_pool_fwd(int dtype, const void* x, int ldx, void* avg, int lda, void* mx, int ldm, int32_t* argmax,
+                                   int N, int64_t HW, int C, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(x && avg && mx && argmax && ldx >= Cp && lda >= Cp && ldm >= Cp, "bad arguments");
+    dim3 grid(Cp / V, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) global_pool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, ldx, (float*)avg, lda, (float*)mx, ldm, argmax, HW, Cp);
+    else global_pool_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, (bf16_t*)avg, lda, (bf16_t*)mx, ldm, argmax, HW, Cp);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ydl_global_pool_bwd(int dtype, const void* davg, int lda, const void* dmx, int ldm, const int32_t* argmax,
+                                   void* dx, int lddx, int accumulate, int N, int64_t HW, int C, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(dx && argmax && lddx >= Cp && (davg || dmx), "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = sgrid((long long)N * HW * (Cp / V));
+    if (dtype == YDL_F32) global_pool_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)davg, lda, (const float*)dmx, ldm, argmax, (float*)dx, lddx, accumulate, N, HW, Cp);
+    else global_pool_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)davg, lda, (const bf16_t*)dmx, ldm, argmax, (bf16_t*)dx, lddx, accumulate, N, HW, Cp);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// gate[n][c] = sigmoid(a[n][c] + b[n][c]);   backward: da (+)= dgate*g*(1-g), db likewise
+template <typename T>
+__global__ void gate_fwd_kernel(const T* a, int lda, const T* b, int ldb, float* gate, int N, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * C) {
+        int n = i / C, c = i % C;
+        gate[i] = sigmoid_f(ET<T>::ld(a + (size_t)n * lda + c) + ET<T>::ld(b + (size_t)n * ldb + c));
+    }
+}
+template <typename T>
+__global__ void gate_bwd_kernel(const float* gate, const float* dgate, T* da, int lda, int acc_a, T* db, int ldb, int acc_b, int N, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * C) {
+        int n = i / C, c = i % C;
+        float g = gate[i];
+        float d = dgate[i] * g * (1.f - g);
+        T* pa = da + (size_t)n * lda + c;
+        T* pb = db + (size_t)n * ldb + c;
+        ET<T>::st(pa, acc_a ? ET<T>::ld(pa) + d : d);
+        ET<T>::st(pb, acc_b ? ET<T>::ld(pb) + d : d);
+    }
+}
+extern "C" int ydl_gate_fwd(int dtype, const void* a, int lda, const void* b, int ldb, float* gate, int N, int C, void* stream) {
+    YDL_CHECK(a && b && gate, "null pointer");
+    int grid = (N * C + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) gate_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)a, lda, (const float*)b, ldb, gate, N, C);
+    else gate_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)a, lda, (const bf16_t*)b, ldb, gate, N, C);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ydl_gate_bwd(int dtype, const float* gate, const float* dgate, void* da, int lda, int acc_a, void* db, int ldb,
+                            int acc_b, int N, int C, void* stream) {
+    YDL_CHECK(gate && dgate && da && db, "null pointer");
+    int grid = (N * C + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) gate_bwd_kernel<float><<<grid, 256, 0, st>>>(gate, dgate, (float*)da, lda, acc_a, (float*)db, ldb, acc_b, N, C);
+    else gate_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(gate, dgate, (bf16_t*)da, lda, acc_a, (bf16_t*)db, ldb, acc_b, N, C);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[n][c] = sum_p a[n,p,c] * b[n,p,c]
+template <typename T>
+__global__ __launch_bounds__(256) void channel_dot_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
+                                                          float* __restrict__ out, long long HW, int C) {
+    constexpr int V = ET<T>::V;
+    const int n = blockIdx.y, c = blockIdx.x * V;
+    float s[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    for (long long p = threadIdx.x; p < HW; p += 256) {
+        float x[V], y[V];
+        unpack16<T>(*(const uint4*)(a + ((size_t)n * HW + p) * lda + c), x);
+        unpack16<T>(*(const uint4*)(b + ((size_t)n * HW + p) * ldb + c), y);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] += x[e] * y[e];
+    }
+    __shared__ float ss[4][8];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        float v = wave_sum(s[e]);
+        if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6][e] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < V && c + threadIdx.x < C)
+        out[(size_t)n * C + c + threadIdx.x] = ss[0][threadIdx.x] + ss[1][threadIdx.x] + ss[2][threadIdx.x] + ss[3][threadIdx.x];
+}
+extern "C" int ydl_channel_dot(int dtype, const void* a, int lda, const void* b, int ldb, float* out, int N, int64_t HW, int C,
+                               void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(a && b && out && lda >= Cp && ldb >= Cp, "bad arguments");
+    dim3 grid(Cp / V, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) channel_dot_kernel<float><<<grid, 256, 0, st>>>((const float*)a, lda, (const float*)b, ldb, out, HW, C);
+    else channel_dot_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)a, lda, (const bf16_t*)b, ldb, out, HW, C);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

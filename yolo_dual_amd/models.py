@@ -24,7 +24,7 @@ import torch.nn as nn
 import yaml
 
 from . import _lib as L
-from .modules import (BasicBlock, Bottleneck, BottleneckBlock, C2f, C3, C3Common, C3k2, Concat, Conv, MaxPool2d,
+from .modules import (GAM, BasicBlock, Bottleneck, BottleneckBlock, C2f, C3, C3Common, C3k2, Concat, Conv, MaxPool2d,
                       SegmentHead, SPPF, Upsample, YdlModule, run_region)
 from .tape import Tape, Var
 
@@ -120,6 +120,8 @@ class _YamlSegModel(YdlModule):
             return Concat(*args), c1
         if module == "nn.Softmax":
             return Softmax(*(args if args else [1])), c1
+        if module == "GAM":
+            return GAM(c1, *args), c1
         if module not in table:
             raise NotImplementedError(f"unknown {where} module: {module}")
         return table[module](c1, *args), args[0]

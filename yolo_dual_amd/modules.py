@@ -21,7 +21,7 @@ from . import _lib as L
 from . import config
 from .tape import Tape, Var, round_up, _p, _stream
 
-__all__ = ["autopad", "Conv", "C3", "C3Common", "Bottleneck", "C2f", "C3k2", "SPPF", "Concat", "Upsample",
+__all__ = ["autopad", "Conv", "C3", "C3Common", "Bottleneck", "C2f", "C3k2", "GAM", "SPPF", "Concat", "Upsample",
            "BasicBlock", "BottleneckBlock", "SegmentHead", "run_region"]
 
 
@@ -498,6 +498,27 @@ class C2f(YdlModule):
         if self.add:
             return self.cv2._fwd(tape, cat, res=x, res_mode=L.RES_AFTER_ACT)
         return self.cv2._fwd(tape, cat)
+
+
+class GAM(YdlModule):
+    """yolo9 global-aggregation channel attention (unet-lite/yolo9-seg/seg_diceloss_yolov9.py:475-510):
+    x * sigmoid(conv2(avgpool(conv1 x)) + conv3(maxpool(conv1 x))).  conv1 runs twice like the reference (its BN
+    running statistics advance twice per step).  Must be built as ``GAM(c)``: the shipped yaml's ``GAM [512]`` binds
+    k=512 and cannot be constructed."""
+
+    def __init__(self, c, k=1, s=1, e=0.25):
+        super().__init__()
+        c_ = int(c * e)
+        self.conv1 = Conv(c, c_, k, s)
+        self.conv2 = Conv(c_, c, k, s, act=False)
+        self.conv3 = Conv(c_, c, k, s, act=False)
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        y1 = tape.global_pool(self.conv1._fwd(tape, x), "avg")
+        y1 = self.conv2._fwd(tape, y1)
+        y2 = tape.global_pool(self.conv1._fwd(tape, x), "max")
+        y2 = self.conv3._fwd(tape, y2)
+        return tape.gate_mul(x, y1, y2)
 
 
 class SPPF(YdlModule):

@@ -442,6 +442,58 @@ class Tape:
         L.call("ydl_softmax_bwd", x.dt, _p(p), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, x.rep[0], x.rep[1],
                _stream())
 
+    # ------------------------------------------------------------------ GAM pieces
+    def global_pool(self, x: Var, kind: str) -> Var:
+        """AdaptiveAvgPool2d(1) / AdaptiveMaxPool2d(1) -> (N, C, 1, 1)"""
+        x = self.materialize(x)
+        avg = self.new(x.N, x.C, 1, 1, zero=True)
+        mx = self.new(x.N, x.C, 1, 1, zero=True)
+        amax = torch.empty((x.N, round_up(x.C, 8)), dtype=torch.int32, device=self.device)
+        HW = x.H * x.W
+        L.call("ydl_global_pool_fwd", x.dt, _p(x.t), x.ld, _p(avg.t), avg.ld, _p(mx.t), mx.ld, _p(amax), x.N, HW, x.C,
+               _stream())
+        out = avg if kind == "avg" else mx
+        if self.record:
+            def bw():
+                if not out.is_set() or not x.need:
+                    return
+                g = self._gbuf(out)
+                gx, acc = self.grad_target(x)
+                L.call("ydl_global_pool_bwd", x.dt, _p(g) if kind == "avg" else None, out.ld,
+                       _p(g) if kind == "max" else None, out.ld, _p(amax), _p(gx), x.ld, acc, x.N, HW, x.C, _stream())
+            self.bw.append(bw)
+        return out
+
+    def gate_mul(self, x: Var, a: Var, b: Var) -> Var:
+        """out = x * sigmoid(a + b) with a, b of shape (N, C, 1, 1) (GAM: the bilinear expansion of a 1x1 map is constant)"""
+        x = self.materialize(x)
+        gate = torch.empty((x.N, x.C), dtype=torch.float32, device=self.device)
+        L.call("ydl_gate_fwd", x.dt, _p(a.t), a.ld, _p(b.t), b.ld, _p(gate), x.N, x.C, _stream())
+        out = self.scale_channels(x, gate)
+        if self.record:
+            def bw():
+                if not out.is_set():
+                    return
+                dout = self._gbuf(out)
+                st = _stream()
+                HW = x.H * x.W
+                dgate = torch.empty((x.N, x.C), dtype=torch.float32, device=self.device)
+                L.call("ydl_channel_dot", x.dt, _p(dout), out.ld, _p(x.t), x.ld, _p(dgate), x.N, HW, x.C, st)
+                ga, acca = self.grad_target(a)
+                gb, accb = self.grad_target(b)
+                L.call("ydl_gate_bwd", x.dt, _p(gate), _p(dgate), _p(ga), a.ld, acca, _p(gb), b.ld, accb, x.N, x.C, st)
+                if x.need:
+                    if x.is_set():
+                        tmp = self.new_like(x)
+                        L.call("ydl_scale_channels", x.dt, _p(dout), out.ld, _p(gate), _p(tmp.t), tmp.ld, x.N, HW, x.C, st)
+                        gx, acc = self.grad_target(x)
+                        L.call("ydl_copy2d", x.dt, _p(tmp.t), tmp.ld, _p(gx), x.ld, x.npix, x.C, 1, st)
+                    else:
+                        gx, _ = self.grad_target(x)
+                        L.call("ydl_scale_channels", x.dt, _p(dout), out.ld, _p(gate), _p(gx), x.ld, x.N, HW, x.C, st)
+            self.bw.append(bw)
+        return out
+
     def scale_channels(self, x: Var, gate: torch.Tensor) -> Var:
         x = self.materialize(x)
         out = self.new_like(x)
