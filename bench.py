@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="keep wgrad on the main stream")
     ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
     args = ap.parse_args()
 
@@ -108,6 +109,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     ydl.set_compute_dtype(args.dtype)
+    if args.no_overlap:
+        ydl.config.set_overlap_wgrad(False)
 
     torch.manual_seed(0)
     model = ydl.YOLOv5Seg(load_cfg()).to(dev).train()

@@ -1,7 +1,7 @@
 """Process-wide settings of the HIP path."""
 from __future__ import annotations
 
-_STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True, "fuse_siblings": True}
+_STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True, "fuse_siblings": True, "overlap_wgrad": True}
 
 
 def set_compute_dtype(name: str) -> None:
@@ -32,6 +32,15 @@ def fuse_siblings() -> bool:
 
 def set_fuse_siblings(on: bool) -> None:
     _STATE["fuse_siblings"] = bool(on)
+
+
+def overlap_wgrad() -> bool:
+    """run weight-gradient kernels on a second stream, concurrently with the input-gradient chain"""
+    return _STATE["overlap_wgrad"]
+
+
+def set_overlap_wgrad(on: bool) -> None:
+    _STATE["overlap_wgrad"] = bool(on)
 
 
 def weight_epoch() -> int:

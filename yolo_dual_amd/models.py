@@ -106,7 +106,23 @@ class _YamlSegModel(YdlModule):
         self.backbone, self.backbone_out_chs = self._build_backbone(self.yaml["backbone"])
         self.head, self.head_out_chs = self._build_head(self.yaml["head"], self.backbone_out_chs)
         _kaiming_init(self, self.init_nonlinearity)
+        self._dead_head = self._find_dead_head_layers()
         self._log_model_info()
+
+    def _find_dead_head_layers(self):
+        """head layers whose output never reaches the model output (absolute ``from`` indices leave whole
+        sub-chains of the yaml head unused).  They are still executed — their BatchNorm running statistics are part
+        of the reference's state — but on the side stream, concurrently with the live path."""
+        nb, head = len(self.yaml["backbone"]), self.yaml["head"]
+        live = {nb + len(head) - 1}
+        for i in range(len(head) - 1, -1, -1):
+            a = nb + i
+            if a not in live:
+                continue
+            f = head[i][0]
+            for src in (f if isinstance(f, list) else [f]):
+                live.add(src if src >= 0 else a + src)
+        return {i for i in range(len(head)) if nb + i not in live}
 
     # builders: ``Module(c1, *args)``; the yaml ``number`` column and the multiples are ignored (T3)
     def _make(self, table, module: str, c1: int, args, where: str):
@@ -159,13 +175,26 @@ class _YamlSegModel(YdlModule):
             x = layer._fwd(tape, x)
             outs.append(x)
         n_head = len(self.head)
+        from . import config as _cfg
+        from .tape import side_stream
+        use_side = bool(self._dead_head) and _cfg.overlap_wgrad()
+        main = torch.cuda.current_stream()
+        side = side_stream(tape.device) if use_side else None
         for i, (layer, (from_, _num, _module, _args)) in enumerate(zip(self.head, self.yaml["head"])):
             inp = [outs[f] for f in from_] if isinstance(from_, list) else outs[from_]
+            if use_side and i in self._dead_head:
+                side.wait_stream(main)                      # inputs come from layers already enqueued on main
+                with torch.cuda.stream(side):
+                    outs.append(layer._fwd(tape, inp) if not isinstance(layer, Softmax) else tape.softmax(inp))
+                tape._side_fwd = True
+                continue
             if isinstance(layer, Softmax):
                 H, W = self.img_size
                 if i == n_head - 1 and (inp.LH, inp.LW) == (H, W):
                     p = tape.softmax_nchw(inp)          # final layer, already at img_size: write NCHW f32 directly
                     tape.ext = (inp, p)
+                    if use_side:
+                        main.wait_stream(side)          # the dead branch has finished before the region returns
                     return p
                 x = tape.softmax(inp)
             else:
@@ -174,6 +203,8 @@ class _YamlSegModel(YdlModule):
         H, W = self.img_size
         if (x.LH, x.LW) != (H, W):                          # T7: always resized to the hard-coded img_size
             x = tape.resize(x, H, W, L.RESIZE_BILINEAR)
+        if use_side:
+            main.wait_stream(side)
         return x
 
     def _seed_external(self, tape: Tape, gout: torch.Tensor) -> None:

@@ -89,6 +89,9 @@ class GradBucketReducer:
     def _launch(self, bi: int) -> None:
         b = self._plan[bi]
         view = self.opt.grads_arena[b["a"]:b["b"]]
+        if view.is_cuda:        # weight gradients are produced on the side stream (tape.side_stream)
+            from .tape import side_stream
+            torch.cuda.current_stream().wait_stream(side_stream(view.device))
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._launched.append((b["a"], b["b"]))
 

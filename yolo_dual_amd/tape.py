@@ -28,6 +28,19 @@ def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """second HIP stream per device: weight-gradient kernels run here, concurrently with the input-gradient chain on
+    the main stream (both only read dy; small layers do not fill 256 CUs on their own)"""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -108,6 +121,7 @@ class Tape:
         self.record = record
         self.bw: List[Callable[[], None]] = []
         self.touched_params: List[torch.nn.Parameter] = []
+        self._side_used = False
         self.ext = None      # (Var, tensor) of a region whose external output was written directly (softmax head)
 
     # ------------------------------------------------------------------ buffers
@@ -204,6 +218,9 @@ class Tape:
         for fn in reversed(self.bw):
             fn()
         self.bw.clear()
+        if self._side_used:
+            torch.cuda.current_stream().wait_stream(side_stream(self.device))   # parameter grads complete
+            self._side_used = False
 
     # ------------------------------------------------------------------ conv + BN + act (+ residual)
     def conv_bn_act(self, x: Var, m, s: int, p: int, act: int, out=None,
@@ -315,8 +332,17 @@ class Tape:
                 if res is not None and res.need and res_mode == L.RES_AFTER_ACT:
                     gbuf, acc = self.grad_target(res)
                     L.call("ydl_copy2d", self.dt, _p(dout), o.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
-            # weight gradient (f32, KRSC) accumulated into the parameter's grad storage
-            m.wgrad(self, gp, x, dy, st2)
+            # weight gradient (f32, KRSC) accumulated into the parameter's grad storage; on the side stream when the
+            # input gradient is needed too, so wgrad and dgrad of a layer overlap
+            from . import config as _cfg
+            if x.need and _cfg.overlap_wgrad():
+                side = side_stream(self.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    m.wgrad(self, gp, x, dy, _stream())
+                self._side_used = True
+            else:
+                m.wgrad(self, gp, x, dy, st2)
             if x.need:
                 gx, acc = self.grad_target(x)
                 L.call("ydl_conv_dgrad", gp, self.dt, _p(dy.t), _p(wt), _p(gx), acc, st2)
