@@ -94,20 +94,25 @@ __device__ __forceinline__ void row_reduce(float (&v)[NV], int lrow) {
     }
 }
 
-// BM = pixel tile (64 or 128), BN = output-channel tile (16, 64 or 128).  256 threads = 4 waves, each wave
-// owns BM/4 pixels x all BN channels.
+// BM = pixel tile (64 or 128), BN = output-channel tile (16, 64 or 128), NW = waves per CTA (4 or 8).
+// Waves form a WP(=4, pixels) x WN(=NW/4, channels) grid: a wave owns BM/4 pixels x BN/WN channels.  The 8-wave
+// form halves the accumulators and LDS fragment reads per wave and doubles the waves per SIMD at the same LDS
+// footprint (more MFMA/VALU/LDS overlap between co-resident waves).
 //
 // Loader (the main loop is issue-bound on VALU if addresses are derived per K-step, so everything that does not
 // depend on k is hoisted): per row a 32-bit byte offset of its (0,0) tap and a 64-bit tap-validity mask are computed
 // once; a K-step adds one table entry (tap delta) and selects "offset or 0xFFFFFFFF" — the loads are raw buffer
 // loads whose range check returns zeros for the padding taps and the tail rows, so there is no branch.
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+template <typename T, int BM, int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     constexpr int V = ET<T>::V;
     constexpr int ES = sizeof(T);
-    constexpr int AR = BM / 32;                 // A rows per thread
-    constexpr int BR = (BN + 31) / 32;          // B rows per thread
-    constexpr int CT = BN / 16;                 // cout tiles per wave
+    constexpr int RPP = NW * 8;                 // tile rows covered by one loader pass (threads / 8 chunks)
+    constexpr int AR = BM / RPP;                // A rows per thread
+    constexpr int BR = (BN + RPP - 1) / RPP;    // B rows per thread
+    constexpr int WN = NW / 4;                  // wave groups along output channels
+    constexpr int BNW = BN / WN;                // channels per wave
+    constexpr int CT = BNW / 16;                // cout tiles per wave
     constexpr int PT = BM / 64;                 // pixel tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                           // [2][BM][ROWB]
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
+    const int wc = wave % WN, wp = wave / WN;   // channel group / pixel group of this wave
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int mtile = tile / p.grid_n, ntile = tile - mtile * p.grid_n;     // N-tiles of one pixel tile are neighbours
     const int m0 = mtile * BM;
@@ -136,12 +142,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
 
     const int q = t & 7;        // chunk column
-    const int r = t >> 3;       // row 0..31
+    const int r = t >> 3;       // row 0..RPP-1
     unsigned rowoff[AR];
     int ih0[AR], iw0[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        int m = m0 + r + 32 * i;
+        int m = m0 + r + RPP * i;
         rowoff[i] = 0;
         ih0[i] = -100000;          // tail rows: every tap fails the range test => zeros
         iw0[i] = 0;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     bool bvalid[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        int row = r + 32 * i;
+        int row = r + RPP * i;
         int co = n0 + row;
         bvalid[i] = row < BN && co < p.Cout;
         browoff[i] = (unsigned)co * (unsigned)(p.Ttot * p.Kc * ES);
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     unsigned char* const stB = sB + r * ROWB + q * 16;
     auto sstore = [&](int buf, const uint4 (&xa)[AR], const uint4 (&xb)[BR]) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *(uint4*)(stA + buf * (BM * ROWB) + i * 32 * ROWB) = xa[i];
+        for (int i = 0; i < AR; ++i) *(uint4*)(stA + buf * (BM * ROWB) + i * RPP * ROWB) = xa[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            if (r + 32 * i < BN) *(uint4*)(stB + buf * (BN * ROWB) + i * 32 * ROWB) = xb[i];
+            if (r + RPP * i < BN) *(uint4*)(stB + buf * (BN * ROWB) + i * RPP * ROWB) = xb[i];
     };
 
     f32x4 acc[CT][PT];
@@ -220,8 +226,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     sstore(0, ra[0], rb[0]);
     __syncthreads();
     const int lrow = lane & 15, lk = (lane >> 4) * 16;
-    const unsigned char* const fa = sB + lrow * ROWB + lk;
-    const unsigned char* const fb = sA + (wave * (BM / 4) + lrow) * ROWB + lk;
+    const unsigned char* const fa = sB + (wc * BNW + lrow) * ROWB + lk;
+    const unsigned char* const fb = sA + (wp * (BM / 4) + lrow) * ROWB + lk;
     for (int kk0 = 0; kk0 < nk; kk0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int cq = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-        int m = m0 + wave * (BM / 4) + j * 16 + lrow;
+        int m = m0 + wp * (BM / 4) + j * 16 + lrow;
         if (m < p.M) {
             int gw = m % p.Wg;
             int tmp = m / p.Wg;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             T* dst = Cg + pix * p.ldc;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                int co = n0 + c * 16 + cq;
+                int co = n0 + wc * BNW + c * 16 + cq;
                 if (co + 3 < p.Cst) {
                     float v[4] = {acc[c][j][0], acc[c][j][1], acc[c][j][2], acc[c][j][3]};
                     if constexpr (sizeof(T) == 4) {
@@ -317,12 +323,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             }
         row_reduce<NV>(v, lrow);
         // after the reduce, slot tt of lane lrow holds value index (tt << 4 | lrow) (NV >= 16) or (lrow & (NV-1))
-        auto chan_of = [&](int idx) { return (idx >> 2) * 16 + lgrp * 4 + (idx & 3); };
+        auto chan_of = [&](int idx) { return wc * BNW + (idx >> 2) * 16 + lgrp * 4 + (idx & 3); };
         if (NV >= 16) {
 #pragma unroll
-            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wave * BN + chan_of((tt << 4) | lrow)] = v[tt];
+            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wp * BN + chan_of((tt << 4) | lrow)] = v[tt];
         } else if (lrow < NV) {
-            red[wave * BN + chan_of(lrow)] = v[0];
+            red[wp * BN + chan_of(lrow)] = v[0];
         }
         __syncthreads();
         float tot = 0.f;
@@ -335,11 +341,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float mu = smean[c * 16 + cq + e];
+                float mu = smean[wc * BNW + c * 16 + cq + e];
                 float t2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < PT; ++j) {
-                    int m = m0 + wave * (BM / 4) + j * 16 + lrow;
+                    int m = m0 + wp * (BM / 4) + j * 16 + lrow;
                     float d = acc[c][j][e] - mu;
                     t2 += (m < p.M) ? d * d : 0.f;
                 }
@@ -349,9 +355,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         __syncthreads();   // everyone has read smean/red before red is overwritten
         if (NV >= 16) {
 #pragma unroll
-            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wave * BN + chan_of((tt << 4) | lrow)] = v[tt];
+            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wp * BN + chan_of((tt << 4) | lrow)] = v[tt];
         } else if (lrow < NV) {
-            red[wave * BN + chan_of(lrow)] = v[0];
+            red[wp * BN + chan_of(lrow)] = v[0];
         }
         __syncthreads();
         if (t < BN && n0 + t < p.Cout) {
@@ -366,17 +372,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NW = 4>
 static int launch_igemm(IgemmArgs a, hipStream_t st) {
     a.grid_n = (a.Cst + BN - 1) / BN;
     dim3 grid(((a.M + BM - 1) / BM) * a.grid_n);
     size_t smem = 2 * (BM + BN) * ROWB + 3 * MAXTAPS * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    igemm_kernel<T, BM, BN><<<grid, 256, smem, st>>>(a);
+    igemm_kernel<T, BM, BN, NW><<<grid, NW * 64, smem, st>>>(a);
     YDL_LAUNCH_CHECK();
     return 0;
 }
@@ -401,10 +407,11 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = 
     TileCfg c = pick_cfg(a.M, a.Cst);
     if (force_bm) c.BM = force_bm;
     if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
-    if (c.BM == 128 && c.BN == 128) return launch_igemm<T, 128, 128>(a, st);
+    static const int nw8 = getenv("YDL_NW8") ? atoi(getenv("YDL_NW8")) : 1;
+    if (c.BM == 128 && c.BN == 128) return nw8 ? launch_igemm<T, 128, 128, 8>(a, st) : launch_igemm<T, 128, 128, 4>(a, st);
     if (c.BM == 128 && c.BN == 64) return launch_igemm<T, 128, 64>(a, st);
     if (c.BM == 128 && c.BN == 16) return launch_igemm<T, 128, 16>(a, st);
-    if (c.BM == 64 && c.BN == 128) return launch_igemm<T, 64, 128>(a, st);
+    if (c.BM == 64 && c.BN == 128) return nw8 ? launch_igemm<T, 64, 128, 8>(a, st) : launch_igemm<T, 64, 128, 4>(a, st);
     if (c.BM == 64 && c.BN == 64) return launch_igemm<T, 64, 64>(a, st);
     return launch_igemm<T, 64, 16>(a, st);
 }
