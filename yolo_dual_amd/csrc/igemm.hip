@@ -16,7 +16,8 @@
 #ifndef YDL_PF
 #define YDL_PF 1     // deeper register prefetch costs an occupancy step on the 128x128 tile (measured slower)
 #endif
-#define ROWB 144      // LDS row stride in bytes (128 data + 16 pad)
+#define ROWB 144      // LDS row stride in bytes (128 data + 16 pad): wgrad tiles (transposed reads)
+#define GROWB 128     // igemm tiles: unpadded rows, XOR-swizzled chunks
 #define MAXTAPS 64
 
 struct IgemmArgs {
@@ -115,9 +116,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     constexpr int CT = BNW / 16;                // cout tiles per wave
     constexpr int PT = BM / 64;                 // pixel tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                           // [2][BM][ROWB]
-    unsigned char* sB = smem + 2 * BM * ROWB;           // [2][BN][ROWB]
-    int* sTapA = (int*)(smem + 2 * (BM + BN) * ROWB);   // [MAXTAPS] byte delta of the tap in A
+    unsigned char* sA = smem;                           // [2][BM][GROWB]
+    unsigned char* sB = smem + 2 * BM * GROWB;           // [2][BN][GROWB]
+    int* sTapA = (int*)(smem + 2 * (BM + BN) * GROWB);   // [MAXTAPS] byte delta of the tap in A
     int* sTapB = sTapA + MAXTAPS;                        // [MAXTAPS] byte offset of the tap inside a weight row
     int* sTapD = sTapB + MAXTAPS;                        // [MAXTAPS] (dh & 0xffff) | (dw << 16)
 
@@ -204,14 +205,19 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
             xb[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    unsigned char* const stA = sA + r * ROWB + q * 16;
-    unsigned char* const stB = sB + r * ROWB + q * 16;
+    // LDS image: unpadded 128-byte rows, 16-byte chunk q of row r stored at slot q ^ ((r >> 1) & 7).  With the
+    // hardware's ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) a fragment read (16 rows, two neighbouring chunk
+    // columns) then touches 16 distinct 16-byte bank slots of the 256-byte bank row: conflict-free (the former
+    // 144-byte padded rows collided 2-way: 35 % of the LDS cycles were conflict cycles in the PMC profile).
+    const int sw_st = (r >> 1) & 7;
+    unsigned char* const stA = sA + r * GROWB + ((q ^ sw_st) << 4);
+    unsigned char* const stB = sB + r * GROWB + ((q ^ sw_st) << 4);
     auto sstore = [&](int buf, const uint4 (&xa)[AR], const uint4 (&xb)[BR]) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *(uint4*)(stA + buf * (BM * ROWB) + i * RPP * ROWB) = xa[i];
+        for (int i = 0; i < AR; ++i) *(uint4*)(stA + buf * (BM * GROWB) + i * RPP * GROWB) = xa[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            if (r + RPP * i < BN) *(uint4*)(stB + buf * (BN * ROWB) + i * RPP * ROWB) = xb[i];
+            if (r + RPP * i < BN) *(uint4*)(stB + buf * (BN * GROWB) + i * RPP * GROWB) = xb[i];
     };
 
     f32x4 acc[CT][PT];
@@ -225,9 +231,12 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         if (u < nk || u == 0) gload(u, ra[u], rb[u]);
     sstore(0, ra[0], rb[0]);
     __syncthreads();
-    const int lrow = lane & 15, lk = (lane >> 4) * 16;
-    const unsigned char* const fa = sB + (wc * BNW + lrow) * ROWB + lk;
-    const unsigned char* const fb = sA + (wp * (BM / 4) + lrow) * ROWB + lk;
+    const int lrow = lane & 15;
+    const int sw_rd = (lrow >> 1) & 7;
+    const int lk0 = (((lane >> 4)) ^ sw_rd) << 4;            // k-step half 0: logical chunk (lane>>4)
+    const int lk1 = (((lane >> 4) + 4) ^ sw_rd) << 4;        // k-step half 1: logical chunk 4 + (lane>>4)
+    const unsigned char* const fa = sB + (wc * BNW + lrow) * GROWB;
+    const unsigned char* const fb = sA + (wp * (BM / 4) + lrow) * GROWB;
     for (int kk0 = 0; kk0 < nk; kk0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -235,15 +244,15 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
             if (kk < nk) {
                 const int cur = kk & 1;
                 if (kk + PF < nk) gload(kk + PF, ra[u], rb[u]);      // set u was consumed by the previous sstore
-                const unsigned char* a_base = fa + cur * (BN * ROWB);
-                const unsigned char* b_base = fb + cur * (BM * ROWB);
+                const unsigned char* a_base = fa + cur * (BN * GROWB);
+                const unsigned char* b_base = fb + cur * (BM * GROWB);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     uint4 af[CT], bfr[PT];
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * ROWB + s * 64);
+                    for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * GROWB + (s ? lk1 : lk0));
 #pragma unroll
-                    for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * ROWB + s * 64);
+                    for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * GROWB + (s ? lk1 : lk0));
 #pragma unroll
                     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -376,7 +385,7 @@ template <typename T, int BM, int BN, int NW = 4>
 static int launch_igemm(IgemmArgs a, hipStream_t st) {
     a.grid_n = (a.Cst + BN - 1) / BN;
     dim3 grid(((a.M + BM - 1) / BM) * a.grid_n);
-    size_t smem = 2 * (BM + BN) * ROWB + 3 * MAXTAPS * sizeof(int);
+    size_t smem = 2 * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
