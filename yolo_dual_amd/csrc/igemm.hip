@@ -571,8 +571,20 @@ template <typename T, bool TR>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int V = ET<T>::V;
     constexpr int TE = 128 / sizeof(T);        // elements per 128-byte tile row: 64 bf16 / 32 f32
-    __shared__ __attribute__((aligned(16))) unsigned char sY[WG_BKP * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char sX[WG_BKP * ROWB];
+    // bf16: unpadded 128-byte rows with the 32-byte blocks XOR-swizzled by f(row) = bit1(row) | bit3(row) << 1, which makes
+    // every 32-lane half of a ds_read_b64_tr_b16 (rows {0-3, 8-11} x one block) hit 8 distinct 32-byte bank segments
+    // (the 144-byte padded rows were 2-way conflicting: 1/3 of the LDS cycles).  f32 keeps the padded layout.
+    constexpr int WROW = (sizeof(T) == 2) ? 128 : ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char sY[WG_BKP * WROW];
+    __shared__ __attribute__((aligned(16))) unsigned char sX[WG_BKP * WROW];
+    auto wsw = [](int row, int colbyte) {          // byte offset of (row, colbyte) in a tile
+        if constexpr (sizeof(T) == 2) {
+            const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+            return row * 128 + ((((colbyte >> 5) ^ f) << 5) | (colbyte & 31));
+        } else {
+            return row * ROWB + colbyte;
+        }
+    };
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wi = wave >> 1, wj = wave & 1;   // wave grid over (cout, j)
     const int tile = xcd_remap(blockIdx.x, gridDim.x);      // all tiles of one pixel range share an XCD's L2
@@ -629,8 +641,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         __syncthreads();   // previous stage's LDS reads done
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *(uint4*)(sY + (r + 32 * i) * ROWB + q * 16) = vy[i];
-            *(uint4*)(sX + (r + 32 * i) * ROWB + q * 16) = vx[i];
+            *(uint4*)(sY + wsw(r + 32 * i, q * 16)) = vy[i];
+            *(uint4*)(sX + wsw(r + 32 * i, q * 16)) = vx[i];
         }
         __syncthreads();
         if (p0 + WG_BKP < pend) gload(p0 + WG_BKP);      // next stage in flight while this one is multiplied
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                     unsigned short e[8];
 #pragma unroll
                     for (int x = 0; x < 8; ++x)
-                        e[x] = *(const unsigned short*)(sY + (ks * 32 + g * 8 + x) * ROWB + (wi * 32 + a * 16 + li) * 2);
+                        e[x] = *(const unsigned short*)(sY + wsw(ks * 32 + g * 8 + x, (wi * 32 + a * 16 + li) * 2));
                     af[a] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
                 }
 #pragma unroll
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                     unsigned short e[8];
 #pragma unroll
                     for (int x = 0; x < 8; ++x)
-                        e[x] = *(const unsigned short*)(sX + (ks * 32 + g * 8 + x) * ROWB + (wj * 32 + b * 16 + li) * 2);
+                        e[x] = *(const unsigned short*)(sX + wsw(ks * 32 + g * 8 + x, (wj * 32 + b * 16 + li) * 2));
                     bfv[b] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
                 }
 #pragma unroll
@@ -669,17 +681,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 uint4 af[NT], bfv[NT];
 #pragma unroll
                 for (int a = 0; a < NT; ++a) {
-                    const unsigned char* base = sY + (ks * 32 + g * 8 + lq) * ROWB + (wi * 32 + a * 16 + lp * 4) * 2;
+                    const unsigned char* base = sY + wsw(ks * 32 + g * 8 + lq, (wi * 32 + a * 16 + lp * 4) * 2);
                     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROWB));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * WROW));
                     uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                     af[a] = make_uint4(l2.x, l2.y, h2.x, h2.y);
                 }
 #pragma unroll
                 for (int b = 0; b < NT; ++b) {
-                    const unsigned char* base = sX + (ks * 32 + g * 8 + lq) * ROWB + (wj * 32 + b * 16 + lp * 4) * 2;
+                    const unsigned char* base = sX + wsw(ks * 32 + g * 8 + lq, (wj * 32 + b * 16 + lp * 4) * 2);
                     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROWB));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * WROW));
                     uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                     bfv[b] = make_uint4(l2.x, l2.y, h2.x, h2.y);
                 }
@@ -723,7 +735,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // current one run), pixel decode by multiply-shift (no integer division in the loop).
 //   TCO = 128: waves 2 (cout) x 2 (j), each 64 x 64 = 4 x 4 MFMA tiles;  TCO = 64: waves 1 x 4, each 64 x 32.
 // ======================================================================================================
-#define W2_ROWB 272      // 256 data + 16 pad bytes per LDS row
+#define W2_ROWB 256      // unpadded; 32-byte blocks XOR-swizzled by f(row) = (row & 3) | bit3(row) << 2  (conflict-free tr reads)
+__device__ __forceinline__ int w2sw(int row, int colbyte) {
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    return row * W2_ROWB + ((((colbyte >> 5) ^ f) << 5) | (colbyte & 31));
+}
 
 struct Wgrad2Args {
     const bf16_t* X; const bf16_t* dY; float* dW;
@@ -803,10 +819,10 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < YR; ++i)
-            *(uint4*)(sY + buf * (64 * W2_ROWB) + (yr + (256 / YCH) * i) * W2_ROWB + yq * 16) = vy[i];
+            *(uint4*)(sY + buf * (64 * W2_ROWB) + w2sw(yr + (256 / YCH) * i, yq * 16)) = vy[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *(uint4*)(sX + buf * (64 * W2_ROWB) + (xr + 16 * i) * W2_ROWB + xq * 16) = vx[i];
+            *(uint4*)(sX + buf * (64 * W2_ROWB) + w2sw(xr + 16 * i, xq * 16)) = vx[i];
     };
 
     gload(pbeg);
@@ -817,14 +833,14 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
     for (int p0 = pbeg; p0 < pend; p0 += 64) {
         const bool more = p0 + 64 < pend;
         if (more) gload(p0 + 64);
-        const unsigned char* by = sY + cur * (64 * W2_ROWB) + (g * 8 + lq) * W2_ROWB + (wi * 64 + lp * 4) * 2;
-        const unsigned char* bx = sX + cur * (64 * W2_ROWB) + (g * 8 + lq) * W2_ROWB + (wj * JW + lp * 4) * 2;
+        const unsigned char* by = sY + cur * (64 * W2_ROWB);
+        const unsigned char* bx = sX + cur * (64 * W2_ROWB);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 af[NA], bfv[NB];
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const unsigned char* base = by + ks * 32 * W2_ROWB + a * 32;
+                const unsigned char* base = by + w2sw(ks * 32 + g * 8 + lq, (wi * 64 + a * 16 + lp * 4) * 2);
                 s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * W2_ROWB));
                 uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -832,7 +848,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const unsigned char* base = bx + ks * 32 * W2_ROWB + b * 32;
+                const unsigned char* base = bx + w2sw(ks * 32 + g * 8 + lq, (wj * JW + b * 16 + lp * 4) * 2);
                 s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * W2_ROWB));
                 uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);

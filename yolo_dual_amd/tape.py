@@ -340,6 +340,9 @@ class Tape:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     m.wgrad(self, gp, x, dy, _stream())
+                # dy was allocated on the main stream and dies with this closure: tell the caching allocator that the
+                # side stream still reads it, or the block is handed to the next main-stream allocation too early
+                dy.t.record_stream(side)
                 self._side_used = True
             else:
                 m.wgrad(self, gp, x, dy, st2)
