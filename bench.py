@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="keep wgrad on the main stream")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
     ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
     args = ap.parse_args()
 
@@ -138,6 +139,37 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    mode = "eager"
+
+    def quick_ms(fn, n=6):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    if not args.eager:
+        # Launch-mode selection (outside the timed region).  Two ways to issue the same kernels:
+        #   eager   : ~700 launches/step from Python on two HIP streams (wgrad + dead head branch overlap the main chain);
+        #             fastest when the host keeps up (about 7-8 ms of host time per step on an idle CPU)
+        #   hipgraph: the whole step captured into two HIP graphs on one stream; ~0.1 ms of host time per step
+        # Both are measured for a few steps and the faster one runs the timed region; a refused capture falls back to eager.
+        try:
+            from yolo_dual_amd.graph import GraphedTrainStep
+            t_eager = quick_ms(step)
+            ydl.config.set_overlap_wgrad(False)
+            gstep = GraphedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=2)
+            t_graph = quick_ms(gstep.step)
+            if t_graph < t_eager:
+                eager_step, step, mode = step, gstep.step, "hipgraph"
+            else:
+                ydl.config.set_overlap_wgrad(not args.no_overlap)
+            print(f"[bench] eager {t_eager:.2f} ms/step, hipgraph {t_graph:.2f} ms/step -> {mode}", file=sys.stderr)
+        except Exception as e:          # pragma: no cover
+            ydl.config.set_overlap_wgrad(not args.no_overlap)
+            print(f"[bench] graph capture unavailable, running eager: {e!r}", file=sys.stderr)
+            torch.cuda.synchronize()
 
     def fence():
         torch.cuda.synchronize()
@@ -161,10 +193,19 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
+        # instrumented pass: every C-ABI launch bracketed by events on the stream it is launched on.  The second
+        # stream is switched off here so that a kernel's duration is its own (in the timed region above wgrad and the
+        # dead head branch overlap with the main chain, which inflates per-kernel durations but shortens the step)
+        overlap_was = ydl.config.overlap_wgrad()
+        ydl.config.set_overlap_wgrad(False)
+        if mode == "hipgraph":
+            step = eager_step          # per-kernel events need individual launches
+        step()
         L.profile_begin()
         for _ in range(3):
             step()
         rec = L.profile_end()
+        ydl.config.set_overlap_wgrad(overlap_was)
         if args.profile_json:
             with open(args.profile_json, "w") as fh:
                 json.dump(rec, fh)
@@ -175,11 +216,22 @@ def main():
         tot_ms = sum(f["ms"] for f in fam.values())
         dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, f = dom
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")
+        if os.path.exists(tpath):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
+            try:
+                tj = json.load(open(tpath))
+                ig = [k for k in tj["kernels"] if "igemm_kernel" in k["kernel"]]
+                n_l = sum(k["launches_per_step"] for k in ig)
+                traffic = {"unit": "MB per launch (igemm fwd+dgrad launches, PMC, FETCH_SIZE x2 per the gfx950 note)",
+                           "value": sum(k["fetch_MB"] + k["write_MB"] for k in ig) / max(n_l, 1)}
+            except Exception:
+                traffic = None
         peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
         if f["flops"] > 0:
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": None, "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
+                    "frac": ach / peak, "traffic": traffic, "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
                     "share_of_gpu_time": f["ms"] / tot_ms}
         else:
             roof = {"bound": "hbm", "kernel": name, "achieved": None, "peak": PEAK_HBM, "unit": "GB/s", "frac": None,
@@ -197,7 +249,7 @@ def main():
             "metric": "images/sec at 640x640 bs=16/GPU", "value": ips, "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic", "loss": loss_val, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+            "data": "synthetic", "launch_mode": mode, "loss": loss_val, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "config": {"workload": "YOLOv5-backbone (C3+SPPF) + UNet-lite SegmentHead, fwd+bwd+SGD/EMA step, "
                                    f"{args.size}x{args.size}, bs={args.bs}/GPU, CE+0.5*Dice, 12 classes (BASELINE configs[1])",
                        "global_batch": args.bs * world, "parallelism": f"dp{world}"},

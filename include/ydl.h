@@ -174,6 +174,12 @@ int ydl_sgd_ema_step(float* params, const float* grads, float* momentum, float* 
                      float lr_decay_group, float lr_nodecay_group, float mom, float weight_decay, float grad_scale,
                      int first_step, float ema_decay /* <0: skip EMA */, void* stream);
 
+/* graph-capturable form: hyper_dev = device float[7] {lr_weights, lr_bn, lr_bias, momentum, weight_decay, grad_scale,
+ * ema_decay}; lr_index selects the learning rate of this run (0 weights, 1 BN weights, 2 biases) */
+int ydl_sgd_ema_step_dev(float* params, const float* grads, float* momentum, float* ema,
+                         int64_t n_decay, int64_t n_params, int64_t n_total, const float* hyper_dev,
+                         int lr_index, int use_weight_decay, int first_step, int use_ema, void* stream);
+
 /* ---- evaluation: argmax + confusion matrix (val_diceloss.py:37-75) ---------------------------------- */
 int ydl_confusion_matrix(const float* pred, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                          const int64_t* target, int N, int C, int H, int W, int ignore_index,

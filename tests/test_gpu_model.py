@@ -183,3 +183,43 @@ def test_full_size_properties():
         total.backward()
         opt.step()
     assert items[0] < before, "loss did not decrease on a fixed batch"
+
+
+def test_graph_capture_matches_eager():
+    """the HIP-graph replay of the training step follows the eager trajectory (same kernels, same order)"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd.graph import GraphedTrainStep
+    ydl.set_compute_dtype("bf16")
+    losses = {}
+    for mode in ("eager", "graph"):
+        m = ydl.YOLOv5Seg(_cfg("yolov5_seg.yaml", {"C3_DCN": "C3"}))
+        m.img_size = [128, 128]
+        sd = m.state_dict()
+        fill_state_dict(sd, 5, bn_stats=False)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.937, weight_decay=5e-4)
+        crit = ydl.SegmentationLoss(12, 0.0, CW, "dice", sync=False)
+        gen = torch.Generator("cuda").manual_seed(3)
+        x = torch.rand(4, 3, 128, 128, device="cuda", generator=gen)
+        t = torch.randint(0, 12, (4, 128, 128), device="cuda", generator=gen)
+        rec = []
+        if mode == "eager":
+            for _ in range(6):
+                opt.zero_grad()
+                total, items = crit(m(x), t)
+                total.backward()
+                opt.step()
+                rec.append(float(items[0]))
+        else:
+            g = GraphedTrainStep(m, crit, opt, x, t, warmup=2)      # 2 eager warm-up steps inside
+            rec = [None, None]
+            for _ in range(4):
+                items = g.step()
+                rec.append(float(items[0]))
+            nbt = int(m.state_dict()["backbone.0.bn.num_batches_tracked"])
+            assert nbt == 6, nbt
+            assert opt.updates == 6
+        losses[mode] = rec
+    for a, b in zip(losses["eager"][2:], losses["graph"][2:]):
+        assert abs(a - b) <= 2e-2 * abs(a), (losses)

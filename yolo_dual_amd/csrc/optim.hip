@@ -141,3 +141,47 @@ extern "C" int ydl_sgd_ema_step(float* params, const float* grads, float* moment
     YDL_LAUNCH_CHECK();
     return 0;
 }
+
+
+// Same update with the hyper-parameters read from DEVICE memory, so that the launch can live inside a captured HIP graph
+// while lr / EMA decay change every step.  hyper = {lr_weights, lr_bn, lr_bias, momentum, weight_decay, grad_scale, ema_d}
+__global__ __launch_bounds__(256) void sgd_ema_dev_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                                          float* __restrict__ mombuf, float* __restrict__ ema,
+                                                          long long n_decay, long long n_params, long long n_total,
+                                                          const float* __restrict__ hyper, int lr_idx, int use_wd, int first,
+                                                          int use_ema) {
+    const float lr = hyper[lr_idx], mom = hyper[3], wd = use_wd ? hyper[4] : 0.f, gscale = hyper[5], d = hyper[6];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (long long)gridDim.x * blockDim.x) {
+        float p = params[i];
+        if (i < n_params) {
+            bool dec = i < n_decay;
+            float g = grads[i] * gscale;
+            if (dec && wd != 0.f) g = g + wd * p;
+            float b = first ? g : mom * mombuf[i] + g;
+            mombuf[i] = b;
+            float upd = g + mom * b;
+            p = p - lr * upd;
+            params[i] = p;
+        }
+        if (use_ema && ema != nullptr) {
+            float e = ema[i];
+            e = e * d;
+            e = e + (1.f - d) * p;
+            ema[i] = e;
+        }
+    }
+}
+
+extern "C" int ydl_sgd_ema_step_dev(float* params, const float* grads, float* momentum, float* ema,
+                                    int64_t n_decay, int64_t n_params, int64_t n_total, const float* hyper_dev,
+                                    int lr_index, int use_weight_decay, int first_step, int use_ema, void* stream) {
+    YDL_CHECK(params && grads && momentum && hyper_dev, "null pointer");
+    YDL_CHECK(0 <= n_decay && n_decay <= n_params && n_params <= n_total && lr_index >= 0 && lr_index <= 2, "bad arguments");
+    int grid = (int)((n_total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    sgd_ema_dev_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, momentum, ema, n_decay, n_params, n_total,
+                                                               hyper_dev, lr_index, use_weight_decay, first_step, use_ema);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

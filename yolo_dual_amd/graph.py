@@ -1,0 +1,74 @@
+"""HIP-graph capture of the training step ("HIP streams and graphs instead of a tracing compiler").
+
+The eager path issues ~700 kernel launches per step through Python + ctypes; on a slow or shared host that costs more
+than the GPU work.  ``GraphedTrainStep`` captures
+    G1 = zero_grad + forward + loss + backward        (both HIP streams: the fork/join of the side stream is captured)
+    G2 = fused SGD-nesterov + EMA step                (hyper-parameters read from a device vector)
+with torch.cuda.CUDAGraph (plumbing: capture/replay API and the graph-private memory pool) and replays them; between the
+two graphs the data-parallel all-reduce of the gradient arena runs eagerly.  Host-side bookkeeping that the captured
+kernels cannot do (BatchNorm ``num_batches_tracked``, EMA update counter, learning-rate schedule) is advanced per replay.
+Inputs are static device tensors: copy each new batch into ``imgs`` / ``targets`` before ``step()``."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import config
+from .modules import _BNHolder
+from .optim import FlatSGDEMA
+
+
+class GraphedTrainStep:
+    def __init__(self, model, criterion, optimizer: FlatSGDEMA, imgs: torch.Tensor, targets: torch.Tensor,
+                 dp=None, warmup: int = 3):
+        self.model, self.criterion, self.opt, self.dp = model, criterion, optimizer, dp
+        self.imgs, self.targets = imgs, targets
+        self._bns: List[_BNHolder] = [m for m in model.modules() if isinstance(m, _BNHolder)]
+        if getattr(criterion, "sync", False):
+            raise ValueError("graph capture needs a loss that does not sync: SegmentationLoss(..., sync=False)")
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream()
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):                       # warm-up off the default stream (torch's capture recipe)
+            for _ in range(warmup):
+                self._fwd_bwd()
+                scale = dp.finish() if dp else 1.0
+                optimizer.prepare_step(scale)
+                optimizer.step_device_hyper()
+        cur.wait_stream(s)
+        torch.cuda.synchronize()
+        nbt0 = [bn._nbt_pending for bn in self._bns]
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            self._fwd_bwd(capturing=True)
+        self._nbt_per_replay = [bn._nbt_pending - a for bn, a in zip(self._bns, nbt0)]
+        self.g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+            optimizer.step_device_hyper()
+        # the captured pass did not execute: undo its host-side counters
+        for bn, a in zip(self._bns, nbt0):
+            bn._nbt_pending = a
+
+    def _fwd_bwd(self, capturing: bool = False):
+        self.opt.zero_grad()
+        if self.dp and not capturing:
+            self.dp.begin()
+        out = self.model(self.imgs)
+        loss, items = self.criterion(out, self.targets)
+        loss.backward()
+        self.loss_items = items
+        return items
+
+    def step(self):
+        """one training step; returns the (device-resident) [total, ce, overlap] loss scalars"""
+        self.g1.replay()
+        for bn, k in zip(self._bns, self._nbt_per_replay):
+            bn._nbt_pending += k
+        scale = 1.0
+        if self.dp is not None:
+            scale = self.dp.reduce_now()       # gradients were produced inside the graph: no per-bucket hooks fired
+        self.opt.prepare_step(scale)
+        self.g2.replay()
+        config.bump_weight_epoch()
+        return self.loss_items

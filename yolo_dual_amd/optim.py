@@ -129,6 +129,55 @@ class FlatSGDEMA(torch.optim.Optimizer):
                     out.append((off, off + n))
         return out
 
+    # ------------------------------------------------------------------ graph-capturable step
+    def prepare_step(self, grad_scale: float = 1.0) -> None:
+        """host half of a step: advance the EMA counter and push {lr, momentum, wd, grad_scale, ema decay} to the device
+        vector the captured kernels read (call OUTSIDE the graph, before replaying it)"""
+        lr_bias, lr_w, lr_bn = (g["lr"] for g in self.param_groups)
+        d = 0.0
+        if self.ema_arena is not None:
+            self.updates += 1
+            d = self.ema_decay * (1.0 - math.exp(-self.updates / self.ema_tau))
+        if getattr(self, "_hyper_host", None) is None:
+            self._hyper_host = torch.empty(7, dtype=torch.float32).pin_memory()
+            self._hyper_dev = torch.empty(7, dtype=torch.float32, device=self.params_arena.device)
+        h = self._hyper_host
+        h[0], h[1], h[2] = lr_w, lr_bn, lr_bias
+        h[3], h[4] = self.param_groups[1]["momentum"], self.param_groups[1]["weight_decay"]
+        h[5], h[6] = grad_scale, d
+        self._hyper_dev.copy_(h, non_blocking=True)
+
+    @torch.no_grad()
+    def step_device_hyper(self) -> None:
+        """device half: the same kernels as ``step`` but reading hyper-parameters from ``_hyper_dev`` (capturable)"""
+        st = _stream()
+        pa, ga, ma, ea = self.params_arena, self.grads_arena, self.mom_arena, self.ema_arena
+        use_ema = 1 if ea is not None else 0
+        runs: List[List] = []
+        for p, off, n, gi in self._slots:
+            touched = bool(getattr(p, "_ydl_touched", False))
+            first = touched and not self._has_buf.get(id(p), False)
+            key = (touched, gi, first)
+            if runs and runs[-1][0] == key and runs[-1][2] == off:
+                runs[-1][2] = off + n
+            else:
+                runs.append([key, off, off + n])
+            if touched:
+                self._has_buf[id(p)] = True
+        hp = _p(self._hyper_dev)
+        for (touched, gi, first), a, b in runs:
+            n = b - a
+            eptr = _p(ea[a:b]) if ea is not None else None
+            if touched:
+                L.call("ydl_sgd_ema_step_dev", _p(pa[a:b]), _p(ga[a:b]), _p(ma[a:b]), eptr, n if gi == 0 else 0, n, n,
+                       hp, gi, 1 if gi == 0 else 0, 1 if first else 0, use_ema, st)
+            elif ea is not None:
+                L.call("ydl_sgd_ema_step_dev", _p(pa[a:b]), _p(ga[a:b]), _p(ma[a:b]), eptr, 0, 0, n, hp, 0, 0, 0, 1, st)
+        if ea is not None and self.n_total > self.n_params:
+            a, b = self.n_params, self.n_total
+            L.call("ydl_sgd_ema_step_dev", _p(pa[a:b]), _p(ga), _p(ma), _p(ea[a:b]), 0, 0, b - a, hp, 0, 0, 0, 1, st)
+        config.bump_weight_epoch()
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         lr_bias, lr_w, lr_bn = (g["lr"] for g in self.param_groups)

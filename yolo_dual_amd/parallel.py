@@ -145,3 +145,20 @@ class DataParallel:
 
     def finish(self) -> float:
         return self.reducer.finish()
+
+    def reduce_now(self) -> float:
+        """all-reduce every live gradient range right now (used after a captured forward/backward graph, where the
+        per-bucket launch hooks did not fire); returns the grad_scale for the optimizer"""
+        r = self.reducer
+        if r.world == 1:
+            return 1.0
+        r.begin_step()
+        live = [bool(getattr(p, "_ydl_touched", False)) for p, *_x in r.opt._slots]
+        if r._plan is None or live != r._live:
+            r._build_plan(live)
+        for bi in range(len(r._plan)):
+            r._launch(bi)
+        for h in r._handles:
+            h.wait()
+        r._handles, r._launched = [], []
+        return 1.0 / r.world

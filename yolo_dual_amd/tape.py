@@ -122,6 +122,7 @@ class Tape:
         self.bw: List[Callable[[], None]] = []
         self.touched_params: List[torch.nn.Parameter] = []
         self._side_used = False
+        self._keep: List[Var] = []
         self.ext = None      # (Var, tensor) of a region whose external output was written directly (softmax head)
 
     # ------------------------------------------------------------------ buffers
@@ -221,6 +222,7 @@ class Tape:
         if self._side_used:
             torch.cuda.current_stream().wait_stream(side_stream(self.device))   # parameter grads complete
             self._side_used = False
+        self._keep.clear()
 
     # ------------------------------------------------------------------ conv + BN + act (+ residual)
     def conv_bn_act(self, x: Var, m, s: int, p: int, act: int, out=None,
@@ -340,9 +342,10 @@ class Tape:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     m.wgrad(self, gp, x, dy, _stream())
-                # dy was allocated on the main stream and dies with this closure: tell the caching allocator that the
-                # side stream still reads it, or the block is handed to the next main-stream allocation too early
-                dy.t.record_stream(side)
+                # dy was allocated on the main stream and would die with this closure while the side stream still reads
+                # it: park the reference until the streams are joined at the end of run_backward (graph-capture safe,
+                # unlike Tensor.record_stream)
+                self._keep.append(dy)
                 self._side_used = True
             else:
                 m.wgrad(self, gp, x, dy, st2)
