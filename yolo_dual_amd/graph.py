@@ -40,8 +40,14 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         nbt0 = [bn._nbt_pending for bn in self._bns]
         self.g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1):
-            self._fwd_bwd(capturing=True)
+        if dp is not None:
+            dp.reducer.enabled = False                   # no collective launches from the gradient hooks while capturing
+        try:
+            with torch.cuda.graph(self.g1):
+                self._fwd_bwd(capturing=True)
+        finally:
+            if dp is not None:
+                dp.reducer.enabled = True
         self._nbt_per_replay = [bn._nbt_pending - a for bn, a in zip(self._bns, nbt0)]
         self.g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g2, pool=self.g1.pool()):

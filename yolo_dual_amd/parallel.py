@@ -36,6 +36,7 @@ class GradBucketReducer:
         self._pending: Dict[int, int] = {}
         self._live: Optional[List[bool]] = None
         self._launched: List[Tuple[int, int]] = []
+        self.enabled = True          # switched off while a HIP graph of the step is being captured
         config.add_grad_hook(self._on_grad)
 
     def close(self) -> None:
@@ -74,7 +75,7 @@ class GradBucketReducer:
 
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p) -> None:
-        if self.world == 1 or self._plan is None:
+        if self.world == 1 or self._plan is None or not self.enabled:
             return
         si = self._slot_of.get(id(p))
         if si is None:
