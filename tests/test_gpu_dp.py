@@ -1,0 +1,104 @@
+"""GPU, 2 ranks sharing cuda:0 over gloo (RCCL needs one device per rank; the box has one): the data-parallel training
+step with the real kernels — bucketed all-reduce from the wgrad/BN-backward hooks (eager) and the post-graph reduction
+(HIP-graph mode) keep the replicas identical, and the averaged gradient is what the optimizer applies."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import yaml
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, use_graph, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import yolo_dual_amd as ydl
+        from oracle.fill import fill_state_dict
+        from yolo_dual_amd.graph import GraphedTrainStep
+        from yolo_dual_amd.parallel import DataParallel
+        torch.cuda.set_device(0)
+        ydl.set_compute_dtype("bf16")
+        cfg = yaml.safe_load(open(os.path.join(CFG, "yolov5_seg.yaml")))
+        for sec in ("backbone", "head"):
+            for l in cfg[sec]:
+                if l[2] == "C3_DCN":
+                    l[2] = "C3"
+        m = ydl.YOLOv5Seg(cfg)
+        m.img_size = [64, 64]
+        sd = m.state_dict()
+        fill_state_dict(sd, 11 + rank, bn_stats=False)          # replicas start different: broadcast must fix it
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.937, weight_decay=5e-4, ema=(rank == 0))
+        dp = DataParallel(m, opt, bucket_bytes=1 << 20)
+        cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+        crit = ydl.SegmentationLoss(12, 0.0, cw, "dice", sync=False)
+        gen = torch.Generator("cuda").manual_seed(100 + rank)      # different data per rank
+        x = torch.rand(2, 3, 64, 64, device="cuda", generator=gen)
+        t = torch.randint(0, 12, (2, 64, 64), device="cuda", generator=gen)
+
+        def eager_step():
+            opt.zero_grad()
+            dp.begin()
+            total, items = crit(m(x), t)
+            total.backward()
+            opt.step(grad_scale=dp.finish())
+            return items
+
+        if use_graph:
+            g = GraphedTrainStep(m, crit, opt, x, t, dp=dp, warmup=2)
+            for _ in range(2):
+                items = g.step()
+        else:
+            for _ in range(3):
+                items = eager_step()
+        torch.cuda.synchronize()
+        # replicas identical (parameters; BN buffers are per-rank by design, like nn.DataParallel replicas)
+        n = opt.n_params
+        mine = opt.params_arena[:n].clone()
+        ref = mine.clone()
+        dist.broadcast(ref, src=0)
+        same = bool(torch.equal(mine, ref))
+        if not same:
+            bad = []
+            for p_, off, n_, g_ in opt._slots:
+                d = float((mine[off:off + n_] - ref[off:off + n_]).abs().max())
+                if d > 0:
+                    bad.append((off, n_, g_, d))
+            print("DIVERGED slots:", len(bad), "of", len(opt._slots), bad[:6], bad[-3:], flush=True)
+        finite = bool(torch.isfinite(mine).all()) and bool(torch.isfinite(torch.stack([i.float() for i in items])).all())
+        q.put((rank, "ok" if (same and finite) else f"fail same={same} finite={finite}"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_data_parallel_on_one_gpu(use_graph):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

@@ -52,9 +52,11 @@ class GraphedTrainStep:
         self.g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g2, pool=self.g1.pool()):
             optimizer.step_device_hyper()
-        # the captured pass did not execute: undo its host-side counters
+        # the captured pass did not execute: undo its host-side counters, and make eager code re-derive the compute
+        # weights (the capture marked them fresh without running the re-layout kernel)
         for bn, a in zip(self._bns, nbt0):
             bn._nbt_pending = a
+        config.bump_weight_epoch()
 
     def _fwd_bwd(self, capturing: bool = False):
         self.opt.zero_grad()

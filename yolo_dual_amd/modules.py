@@ -243,9 +243,14 @@ class Conv(YdlModule):
         return p.grad
 
     def grad_slot(self, tape: Tape, which: str):
+        """gradient storage of gamma / beta; ``touch_bn`` must be called AFTER the kernel writing it is enqueued (the
+        data-parallel hook may launch the bucket's all-reduce from inside mark_touched)"""
         p = self.bn.weight if which == "gamma" else self.bn.bias
-        config.mark_touched(p)
         return self._grad_of(p), 1
+
+    def touch_bn(self) -> None:
+        config.mark_touched(self.bn.weight)
+        config.mark_touched(self.bn.bias)
 
     def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
         p = self.conv.weight
@@ -364,9 +369,12 @@ class _FusedPair:
 
     def grad_slot(self, tape: Tape, which: str):
         p1, p2 = self._grads(which)
-        config.mark_touched(p1)
-        config.mark_touched(p2)
         return torch.as_strided(p1.grad, (self.c2,), (1,)), 1
+
+    def touch_bn(self) -> None:
+        for which in ("gamma", "beta"):
+            for p in self._grads(which):
+                config.mark_touched(p)
 
     def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
         p1, p2 = self._grads("w")

@@ -334,6 +334,7 @@ class Tape:
                 if res is not None and res.need and res_mode == L.RES_AFTER_ACT:
                     gbuf, acc = self.grad_target(res)
                     L.call("ydl_copy2d", self.dt, _p(dout), o.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
+            m.touch_bn()          # dgamma / dbeta kernels are enqueued: the DP hook may now reduce their bucket
             # weight gradient (f32, KRSC) accumulated into the parameter's grad storage; on the side stream when the
             # input gradient is needed too, so wgrad and dgrad of a layer overlap
             from . import config as _cfg
