@@ -165,6 +165,18 @@ int ydl_seg_loss_bwd(const float* pred, int64_t sn, int64_t sc, int64_t sh, int6
                      int kind, float label_smoothing, float eps, int N, int C, int H, int W,
                      const float* ws, const float* dloss /* device scalar, NULL = 1 */, float* dpred, void* stream);
 
+/* Replicated-prediction variant of the two calls above: the (N, C, H*rep_h, W*rep_w) prediction is the exact nearest
+ * replication of `plow` (N, C, H, W) — the lazily evaluated `Upsample(nearest) -> Conv 1x1 -> Softmax` tail of the yaml
+ * models (seg_diceloss_yolov5.py:588-614 builds it).  target is (N, H*rep_h, W*rep_w) int64.  Same ws layout, same
+ * `losses`; the backward returns dlow[n,c,h,w] = sum over the rep_h*rep_w replicas of d loss / d pred. */
+int ydl_seg_loss_rep_fwd(const float* plow, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                         const int64_t* target, const float* class_weights, int kind, float label_smoothing, float eps,
+                         int N, int C, int H, int W, int rep_h, int rep_w, float* ws, float* losses, void* stream);
+int ydl_seg_loss_rep_bwd(const float* plow, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                         const int64_t* target, const float* class_weights, int kind, float label_smoothing, float eps,
+                         int N, int C, int H, int W, int rep_h, int rep_w, const float* ws,
+                         const float* dloss /* device scalar, NULL = 1 */, float* dlow, void* stream);
+
 /* ---- optimizer: SGD(nesterov) + EMA on flat arenas --------------------------------------------------- */
 /* params/grads/momentum are flat f32 arenas laid out [decay group | no-decay group]; ema spans
  * n_params + n_buffers (BN running stats follow the params in both `params` and `ema`).

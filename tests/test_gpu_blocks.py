@@ -256,6 +256,74 @@ def test_loss_nhwc_strides():
     assert rel_err(logits.grad.cpu(), g.t("glogits")) < 1e-4
 
 
+@pytest.mark.parametrize("kind,ls,rep", [("dice", 0.0, (4, 4)), ("jaccard", 0.1, (2, 3)), ("dice", 0.05, (4, 2))])
+def test_loss_replicated_matches_full(kind, ls, rep):
+    """ydl_seg_loss_rep_* (one thread per stored pixel of a nearest-replicated prediction, labels counted per class)
+    == the full-resolution kernels on the materialised replication: same losses, and dlow == replica-sum of dpred."""
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd.tape import _p, _stream
+    torch.manual_seed(3)
+    N, C, h, w = 3, 12, 9, 14
+    rh, rw = rep
+    low = torch.randn(N, C, h, w, device="cuda").softmax(1).contiguous()
+    full = low.repeat_interleave(rh, 2).repeat_interleave(rw, 3).contiguous()
+    target = torch.randint(0, C, (N, h * rh, w * rw), device="cuda")
+    target[0, :3, :5] = 255                                         # out-of-range labels hit no class in either path
+    cw = torch.rand(C, device="cuda") + 0.5
+    k = L.LOSS_DICE if kind == "dice" else L.LOSS_JACCARD
+    nws = L.lib().ydl_seg_loss_ws_floats(N, C)
+    ws_a, ws_b = torch.zeros(nws, device="cuda"), torch.zeros(nws, device="cuda")
+    la, lb = torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda")
+    g = torch.tensor([0.7], device="cuda")
+    st = _stream()
+    L.call("ydl_seg_loss_fwd", _p(full), *full.stride(), _p(target), h * rh, w * rw, _p(cw), k, ls, 1e-6, N, C, h * rh, w * rw,
+           _p(ws_a), _p(la), st)
+    dfull = torch.empty_like(full)
+    L.call("ydl_seg_loss_bwd", _p(full), *full.stride(), _p(target), h * rh, w * rw, _p(cw), k, ls, 1e-6, N, C, h * rh, w * rw,
+           _p(ws_a), _p(g), _p(dfull), st)
+    L.call("ydl_seg_loss_rep_fwd", _p(low), *low.stride(), _p(target), _p(cw), k, ls, 1e-6, N, C, h, w, rh, rw, _p(ws_b), _p(lb), st)
+    dlow = torch.empty_like(low)
+    L.call("ydl_seg_loss_rep_bwd", _p(low), *low.stride(), _p(target), _p(cw), k, ls, 1e-6, N, C, h, w, rh, rw, _p(ws_b), _p(g),
+           _p(dlow), st)
+    torch.cuda.synchronize()
+    assert torch.allclose(la, lb, rtol=2e-6, atol=0), (la, lb)
+    ref = dfull.view(N, C, h, rh, w, rw).double().sum((3, 5)).float()
+    assert rel_err(dlow.cpu(), ref.cpu()) < 1e-5
+
+
+def test_loss_fast_path_survives_only_untouched_predictions():
+    """the model tags its replicated output; an in-place edit by the caller must switch the loss back to the dense kernels"""
+    import yolo_dual_amd as ydl
+    ydl.set_compute_dtype("f32")
+    torch.manual_seed(0)
+    import os, yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(ydl.__file__), "cfg", "yolov5_seg.yaml")))
+    for sec in ("backbone", "head"):
+        for l in cfg[sec]:
+            l[2] = "C3" if l[2] == "C3_DCN" else l[2]
+    m = ydl.YOLOv5Seg(cfg)
+    m.img_size = [64, 64]
+    m = m.cuda().train()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    t = torch.randint(0, 12, (2, 64, 64), device="cuda")
+    crit = ydl.SegmentationLoss(12, 0.0, None, "dice", sync=False)
+    res = []
+    for mode in ("fast", "dense", "edited"):
+        for p in m.parameters():
+            p.grad = None
+        crit.use_replicated = mode != "dense"
+        pred = m(x)
+        assert getattr(pred, "_ydl_lazy", None) is not None
+        if mode == "edited":
+            pred.mul_(1.0)                       # bumps the version counter: the tag is stale
+        total, _ = crit(pred, t)
+        total.backward()
+        res.append((float(total), torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).cpu()))
+    for tot, gr in res[1:]:
+        assert abs(tot - res[0][0]) <= 2e-6 * abs(res[0][0])
+        assert rel_err(gr, res[0][1]) < 2e-4
+
+
 def test_sgd_ema_flat_optimizer():
     """FlatSGDEMA == smart_optimizer(SGD nesterov) + ModelEMA on the reference's own 3-step trajectory."""
     import torch.nn as nn

@@ -63,6 +63,8 @@ SIGNATURES = {
     "ydl_seg_loss_ws_floats": (_i64, [_i, _i]),
     "ydl_seg_loss_fwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ydl_seg_loss_bwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _vp, _i, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ydl_seg_loss_rep_fwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ydl_seg_loss_rep_bwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ydl_sgd_ema_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "ydl_sgd_ema_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp]),
     "ydl_confusion_matrix": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

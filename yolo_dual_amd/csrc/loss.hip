@@ -388,6 +388,211 @@ extern "C" int ydl_seg_loss_bwd(const float* pred, int64_t sn, int64_t sc, int64
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Replicated-prediction variant.  The yaml models end in  Upsample(nearest, r) -> Conv 1x1 -> Softmax, which this
+// library evaluates lazily at the stored resolution: the (N, C, H*rh, W*rw) prediction is an exact rh x rw
+// replication of `plow` (N, C, H, W).  Every per-pixel term of the loss then depends on the label only, so one thread
+// per STORED pixel reads its rh*rw labels, counts them per class and adds count-weighted terms: the same sums as the
+// full-resolution kernels above (re-associated), at 1/(rh*rw) of the prediction traffic.  The backward returns
+// dlow[n,c,h,w] = sum over the replicas of d loss / d pred, which is what the lazy up-sampling backward needs.
+// ------------------------------------------------------------------------------------------------------
+template <int MC>
+__device__ __forceinline__ void count_labels(const int64_t* __restrict__ target, int n, int h, int w, int Ht, int Wt, int rh, int rw,
+                                             float (&cnt)[MC]) {
+#pragma unroll
+    for (int c = 0; c < MC; ++c) cnt[c] = 0.f;
+    const int64_t* tp = target + ((size_t)n * Ht + (size_t)h * rh) * Wt + (size_t)w * rw;
+    if (rw == 4 && (Wt & 1) == 0) {
+        for (int a = 0; a < rh; ++a) {
+            const longlong2* q = (const longlong2*)(tp + (size_t)a * Wt);
+            longlong2 u0 = q[0], u1 = q[1];
+            int t0 = (int)u0.x, t1 = (int)u0.y, t2 = (int)u1.x, t3 = (int)u1.y;
+#pragma unroll
+            for (int c = 0; c < MC; ++c)
+                cnt[c] += (float)((t0 == c) + (t1 == c) + (t2 == c) + (t3 == c));
+        }
+    } else {
+        for (int a = 0; a < rh; ++a)
+            for (int b = 0; b < rw; ++b) {
+                int t = (int)tp[(size_t)a * Wt + b];
+#pragma unroll
+                for (int c = 0; c < MC; ++c) cnt[c] += (t == c) ? 1.f : 0.f;
+            }
+    }
+}
+
+template <int MC>
+__global__ __launch_bounds__(256) void seg_loss_rep_fwd_kernel(const float* __restrict__ plow, long long sn, long long sc, long long sh,
+                                                               long long sw, const int64_t* __restrict__ target,
+                                                               const float* __restrict__ cw, int C, int H, int W, int rh, int rw,
+                                                               float* __restrict__ part) {
+    const int n = blockIdx.y;
+    const long long HW = (long long)H * W;
+    const int Ht = H * rh, Wt = W * rw;
+    const float rr = (float)(rh * rw);
+    float accI[MC], accP[MC], accT[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) { accI[c] = 0.f; accP[c] = 0.f; accT[c] = 0.f; }
+    float ce_num = 0.f, ce_den = 0.f, sm_num = 0.f;
+    float wv[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) wv[c] = (c < C) ? (cw ? cw[c] : 1.f) : 0.f;
+
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+        int w = (int)(i % W), h = (int)(i / W);
+        const float* pp = plow + n * sn + h * sh + w * sw;
+        float cnt[MC];
+        count_labels<MC>(target, n, h, w, Ht, Wt, rh, rw, cnt);
+        float v[MC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) { v[c] = pp[c * sc]; mx = fmaxf(mx, v[c]); }
+        float s = 0.f;
+        float ex[MC];
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) { ex[c] = expf(v[c] - mx); s += ex[c]; }
+        float lse = mx + logf(s);
+        float inv = 1.f / s;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) {
+                float pc = ex[c] * inv;
+                float wp = wv[c] * pc;
+                accP[c] += rr * wp;
+                accI[c] += cnt[c] * wp;
+                accT[c] += cnt[c];
+                float wn = wv[c] * (lse - v[c]);     // w_c * (-log p_c)
+                sm_num += rr * wn;
+                ce_num += cnt[c] * wn;
+                ce_den += cnt[c] * wv[c];
+            }
+    }
+    __shared__ float red[4][3 * MC + 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+        if (c < C) {
+            float a = wave_sum(accI[c]), b = wave_sum(accP[c]), d = wave_sum(accT[c]);
+            if (lane == 0) { red[wave][c] = a; red[wave][MC + c] = b; red[wave][2 * MC + c] = d; }
+        }
+    {
+        float a = wave_sum(ce_num), b = wave_sum(ce_den), d = wave_sum(sm_num);
+        if (lane == 0) { red[wave][3 * MC] = a; red[wave][3 * MC + 1] = b; red[wave][3 * MC + 2] = d; }
+    }
+    __syncthreads();
+    float* dst = part + ((size_t)n * gridDim.x + blockIdx.x) * (3 * C + 3);
+    if (threadIdx.x < 3 * C + 3) {
+        int k = threadIdx.x;
+        int src = k < 3 * C ? (k / C) * MC + (k % C) : 3 * MC + (k - 3 * C);
+        dst[k] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    }
+}
+
+// sum over the rh*rw replicas of the full-resolution gradient (labels enter through their per-class counts):
+//   S = sum_t cnt_t w_t,  A = sum_t cnt_t w_t aI_t p_t,  G0 = sum_c w_c aP_c p_c,  rr = rh*rw
+//   dlow_c = g0 * [ k_nll (p_c S - cnt_c w_c) + k_sm rr (p_c Wsum - w_c) + 0.5 p_c (rr w_c aP_c + cnt_c w_c aI_c - rr G0 - A) ]
+template <int MC>
+__global__ __launch_bounds__(256) void seg_loss_rep_bwd_kernel(const float* __restrict__ plow, long long sn, long long sc, long long sh,
+                                                               long long sw, const int64_t* __restrict__ target,
+                                                               const float* __restrict__ cw, int C, int H, int W, int rh, int rw,
+                                                               float ls, const float* __restrict__ ws, int N,
+                                                               const float* __restrict__ dloss, float* __restrict__ dlow) {
+    const int n = blockIdx.y;
+    const int NC = N * C;
+    const long long HW = (long long)H * W;
+    const int Ht = H * rh, Wt = W * rw;
+    const float rr = (float)(rh * rw);
+    const float g0 = dloss ? dloss[0] : 1.f;
+    const float ce_den = ws[5 * NC + 1], Wsum = ws[5 * NC + 3];
+    float wv[MC], aI[MC], aP[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        wv[c] = (c < C) ? (cw ? cw[c] : 1.f) : 0.f;
+        aI[c] = (c < C) ? ws[3 * NC + n * C + c] : 0.f;
+        aP[c] = (c < C) ? ws[4 * NC + n * C + c] : 0.f;
+    }
+    const float k_nll = (1.f - ls) / ce_den;
+    const float k_sm = ls > 0.f ? ls / ((float)C * ce_den) : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+        int w = (int)(i % W), h = (int)(i / W);
+        const long long off = n * sn + h * sh + w * sw;
+        float cnt[MC];
+        count_labels<MC>(target, n, h, w, Ht, Wt, rh, rw, cnt);
+        float v[MC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) { v[c] = plow[off + c * sc]; mx = fmaxf(mx, v[c]); }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) { v[c] = expf(v[c] - mx); s += v[c]; }
+        float inv = 1.f / s;
+        float S = 0.f, A = 0.f, G0 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) {
+                v[c] *= inv;
+                float cwc = cnt[c] * wv[c];
+                S += cwc;
+                A += cwc * aI[c] * v[c];
+                G0 += wv[c] * aP[c] * v[c];
+            }
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) {
+                float cwc = cnt[c] * wv[c];
+                float d_ce = k_nll * (v[c] * S - cwc) + k_sm * rr * (v[c] * Wsum - wv[c]);
+                float d_ov = v[c] * (rr * wv[c] * aP[c] + cwc * aI[c] - rr * G0 - A);
+                dlow[off + c * sc] = g0 * (d_ce + 0.5f * d_ov);
+            }
+    }
+}
+
+extern "C" int ydl_seg_loss_rep_fwd(const float* plow, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                    const int64_t* target, const float* class_weights, int kind, float label_smoothing, float eps,
+                                    int N, int C, int H, int W, int rep_h, int rep_w, float* ws, float* losses, void* stream) {
+    YDL_CHECK(plow && target && ws && losses, "null pointer");
+    YDL_CHECK(C >= 1 && C <= MAXC && N >= 1 && H >= 1 && W >= 1 && rep_h >= 1 && rep_w >= 1, "bad sizes (C <= 32)");
+    YDL_CHECK(kind == YDL_LOSS_DICE || kind == YDL_LOSS_JACCARD, "bad loss kind");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(LOSS_BLOCKS_PER_IMAGE, N);
+    float* part = ws + (size_t)5 * N * C + 4;
+    if (C <= 16)
+        seg_loss_rep_fwd_kernel<16><<<grid, 256, 0, st>>>(plow, sn, sc, sh, sw, target, class_weights, C, H, W, rep_h, rep_w, part);
+    else
+        seg_loss_rep_fwd_kernel<32><<<grid, 256, 0, st>>>(plow, sn, sc, sh, sw, target, class_weights, C, H, W, rep_h, rep_w, part);
+    float* img_part = part + (size_t)N * LOSS_BLOCKS_PER_IMAGE * (3 * C + 3);
+    seg_loss_merge1_kernel<<<N, 256, 0, st>>>(ws, N, C, LOSS_BLOCKS_PER_IMAGE, kind, eps, img_part);
+    seg_loss_merge2_kernel<<<1, 64, 0, st>>>(ws, N, C, label_smoothing, class_weights, img_part, losses);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ydl_seg_loss_rep_bwd(const float* plow, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                    const int64_t* target, const float* class_weights, int kind, float label_smoothing, float eps,
+                                    int N, int C, int H, int W, int rep_h, int rep_w, const float* ws, const float* dloss,
+                                    float* dlow, void* stream) {
+    (void)kind; (void)eps;
+    YDL_CHECK(plow && target && ws && dlow, "null pointer");
+    YDL_CHECK(C >= 1 && C <= MAXC && rep_h >= 1 && rep_w >= 1, "bad sizes (C <= 32)");
+    hipStream_t st = (hipStream_t)stream;
+    long long HW = (long long)H * W;
+    int bx = (int)((HW + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    dim3 grid(bx, N);
+    if (C <= 16)
+        seg_loss_rep_bwd_kernel<16><<<grid, 256, 0, st>>>(plow, sn, sc, sh, sw, target, class_weights, C, H, W, rep_h, rep_w,
+                                                          label_smoothing, ws, N, dloss, dlow);
+    else
+        seg_loss_rep_bwd_kernel<32><<<grid, 256, 0, st>>>(plow, sn, sc, sh, sw, target, class_weights, C, H, W, rep_h, rep_w,
+                                                          label_smoothing, ws, N, dloss, dlow);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // argmax + confusion matrix (rows = target, cols = prediction; pixels whose target == ignore_index dropped)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ pred, long long sn, long long sc, long long sh,

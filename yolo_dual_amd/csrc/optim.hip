@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const long lon
 
 extern "C" int ydl_weight_prep_batched(int dtype, const int64_t* desc_dev, int nlayers, void* stream) {
     YDL_CHECK(desc_dev && nlayers > 0, "bad arguments");
-    dim3 grid(128, nlayers);
+    dim3 grid(512, nlayers);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == YDL_F32) weight_prep_batched_kernel<float><<<grid, 256, 0, st>>>((const long long*)desc_dev);
     else weight_prep_batched_kernel<bf16_t><<<grid, 256, 0, st>>>((const long long*)desc_dev);

@@ -18,7 +18,7 @@ from .tape import _p, _stream
 
 class _SegLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, cw, kind, ls, eps):
+    def forward(ctx, pred, target, cw, kind, ls, eps, lazy):
         if pred.device.type != "cuda":
             raise RuntimeError("SegmentationLoss runs on the GPU only (no CPU fallback for the HIP kernels)")
         if pred.dtype != torch.float32:
@@ -30,16 +30,41 @@ class _SegLossFn(torch.autograd.Function):
         Ht, Wt = target.shape[1:]
         ws = torch.empty(L.lib().ydl_seg_loss_ws_floats(N, C), dtype=torch.float32, device=pred.device)
         losses = torch.empty(3, dtype=torch.float32, device=pred.device)
-        sn, sc, sh, sw = pred.stride()
-        L.call("ydl_seg_loss_fwd", _p(pred), sn, sc, sh, sw, _p(target), Ht, Wt, _p(cw), kind, ls, eps,
-               N, C, H, W, _p(ws), _p(losses), _stream())
-        ctx.save_for_backward(pred, target, ws)
+        if lazy is not None and (Ht, Wt) != (H, W):
+            lazy = None
+        ctx.lazy = lazy
+        if lazy is not None:
+            low, (rh, rw) = lazy.low, lazy.rep
+            sn, sc, sh, sw = low.stride()
+            L.call("ydl_seg_loss_rep_fwd", _p(low), sn, sc, sh, sw, _p(target), _p(cw), kind, ls, eps,
+                   N, C, H // rh, W // rw, rh, rw, _p(ws), _p(losses), _stream())
+            ctx.save_for_backward(target, ws)
+            ctx.shape = tuple(pred.shape)
+        else:
+            sn, sc, sh, sw = pred.stride()
+            L.call("ydl_seg_loss_fwd", _p(pred), sn, sc, sh, sw, _p(target), Ht, Wt, _p(cw), kind, ls, eps,
+                   N, C, H, W, _p(ws), _p(losses), _stream())
+            ctx.save_for_backward(pred, target, ws)
         ctx.cw, ctx.kind, ctx.ls, ctx.eps = cw, kind, ls, eps
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
 
     @staticmethod
     def backward(ctx, gtotal, _glosses):
+        g = gtotal.contiguous().float()
+        lazy = ctx.lazy
+        if lazy is not None:
+            target, ws = ctx.saved_tensors
+            low, (rh, rw) = lazy.low, lazy.rep
+            N, C, h, w = low.shape
+            dlow = torch.empty_like(low)
+            sn, sc, sh, sw = low.stride()
+            L.call("ydl_seg_loss_rep_bwd", _p(low), sn, sc, sh, sw, _p(target), _p(ctx.cw), ctx.kind, ctx.ls, ctx.eps,
+                   N, C, h, w, rh, rw, _p(ws), _p(g), _p(dlow), _stream())
+            # the replica-summed gradient travels through the side channel; autograd gets a zero placeholder
+            lazy.dlow = dlow
+            lazy.dummy = g.new_zeros(1).expand(ctx.shape)
+            return lazy.dummy, None, None, None, None, None, None
         pred, target, ws = ctx.saved_tensors
         N, C, H, W = pred.shape
         Ht, Wt = target.shape[1:]
@@ -47,10 +72,9 @@ class _SegLossFn(torch.autograd.Function):
         sn, sc, sh, sw = pred.stride()
         if dpred.stride() != pred.stride():
             dpred = torch.empty_strided(pred.shape, pred.stride(), dtype=pred.dtype, device=pred.device)
-        g = gtotal.contiguous().float()
         L.call("ydl_seg_loss_bwd", _p(pred), sn, sc, sh, sw, _p(target), Ht, Wt, _p(ctx.cw), ctx.kind, ctx.ls, ctx.eps,
                N, C, H, W, _p(ws), _p(g), _p(dpred), _stream())
-        return dpred, None, None, None, None, None
+        return dpred, None, None, None, None, None, None
 
 
 class SegmentationLoss(nn.Module):
@@ -63,6 +87,7 @@ class SegmentationLoss(nn.Module):
         self.label_smoothing = float(label_smoothing)
         self.kind = {"dice": L.LOSS_DICE, "jaccard": L.LOSS_JACCARD}[kind]
         self.sync = sync
+        self.use_replicated = True       # False forces the full-resolution kernels (tests compare the two)
         self.class_weights = None if class_weights is None else torch.as_tensor(class_weights, dtype=torch.float32)
 
     def forward(self, pred: torch.Tensor, target: torch.Tensor) -> Tuple[torch.Tensor, List[float]]:
@@ -73,7 +98,13 @@ class SegmentationLoss(nn.Module):
         cw = self.class_weights
         if cw is not None and cw.device != pred.device:
             cw = self.class_weights = cw.to(pred.device)
-        total, losses = _SegLossFn.apply(pred, target, cw, self.kind, self.label_smoothing, 1e-6)
+        # a prediction that is an exact nearest replication (lazy Upsample -> Conv 1x1 -> Softmax tail) and has not been
+        # edited in place since the model produced it: loss and gradient are evaluated per stored pixel
+        lazy = getattr(pred, "_ydl_lazy", None) if self.use_replicated else None
+        if lazy is not None and (lazy.version != pred._version or pred.dtype != torch.float32
+                                 or not (pred.requires_grad and torch.is_grad_enabled())):
+            lazy = None
+        total, losses = _SegLossFn.apply(pred, target, cw, self.kind, self.label_smoothing, 1e-6, lazy)
         if self.sync:
             return total, losses.tolist()
         return total, [losses[0], losses[1], losses[2]]

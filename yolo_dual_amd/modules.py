@@ -106,7 +106,12 @@ def refresh_weights(fn: nn.Module, tape: Tape) -> None:
 
 def run_region(fn: nn.Module, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
     params = [p for p in fn.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
-    return _Region.apply(fn, len(inputs), *inputs, *params)
+    out = _Region.apply(fn, len(inputs), *inputs, *params)
+    lazy = getattr(getattr(out.grad_fn, "tape", None), "lazy_out", None)
+    if lazy is not None:                # replicated output: let SegmentationLoss work at the stored resolution
+        lazy.version = out._version
+        out._ydl_lazy = lazy
+    return out
 
 
 class YdlModule(nn.Module):

@@ -111,6 +111,17 @@ def _alloc(N: int, C: int, H: int, W: int, tdtype: torch.dtype, device, zero: bo
     return buf.permute(0, 3, 1, 2)[:, :C], ld
 
 
+class LazyOutput:
+    """side channel between a region whose output is a nearest-replicated tensor and SegmentationLoss:
+    ``low`` = the (N, C, H, W) tensor the (N, C, H*rh, W*rw) output replicates, ``version`` = the output's version
+    counter when it was produced (an in-place edit by the caller invalidates the shortcut), ``dlow`` = replica-summed
+    gradient handed back by the loss backward, ``dummy`` = the zero-stride placeholder gradient it returned."""
+    __slots__ = ("low", "rep", "version", "dlow", "dummy")
+
+    def __init__(self, low: torch.Tensor, rep):
+        self.low, self.rep, self.version, self.dlow, self.dummy = low, tuple(rep), -1, None, None
+
+
 class Tape:
     def __init__(self, dtype: str, device, train: bool, record: bool):
         self.dname = dtype
@@ -458,19 +469,42 @@ class Tape:
 
     def softmax_nchw(self, x: Var) -> torch.Tensor:
         """nn.Softmax(1) producing the region's external output directly: f32 NCHW contiguous (no extra pass).
-        The region owner must call softmax_nchw_backward with the incoming gradient."""
+        The region owner must call softmax_nchw_backward with the incoming gradient.
+        When x is a lazily up-sampled tensor the stored-resolution probabilities are kept as well (``self.lazy_out``):
+        SegmentationLoss uses them to evaluate the loss and its gradient per stored pixel (ydl_seg_loss_rep_*)."""
         p = torch.empty((x.N, x.C, x.LH, x.LW), dtype=torch.float32, device=self.device)
         sn, sc, sh, sw = p.stride()
         L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(p), sn, sc, sh, sw, x.N, x.H, x.W, x.C, x.rep[0], x.rep[1],
                _stream())
+        self.lazy_out = None
+        if x.rep != (1, 1) and self.record:
+            plow = torch.empty((x.N, x.C, x.H, x.W), dtype=torch.float32, device=self.device)
+            sn, sc, sh, sw = plow.stride()
+            L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(plow), sn, sc, sh, sw, x.N, x.H, x.W, x.C, 1, 1, _stream())
+            self.lazy_out = LazyOutput(plow, x.rep)
         return p
 
     def softmax_nchw_backward(self, x: Var, p: torch.Tensor, dp: torch.Tensor) -> None:
         dp = dp.detach()
-        if dp.dtype != torch.float32 or dp.stride() != p.stride():
-            dp = dp.float().contiguous()
         gx, acc = self.grad_target(x)
         assert acc == 0
+        lazy = getattr(self, "lazy_out", None)
+        dlow = None
+        if lazy is not None:
+            dlow, lazy.dlow = lazy.dlow, None
+        if dlow is not None:
+            if all(s == 0 for s in dp.stride()) and getattr(lazy, "dummy", None) is not None:
+                # the loss already summed its gradient over the replicas: soft-max backward at the stored resolution
+                lazy.dummy = None
+                sn, sc, sh, sw = lazy.low.stride()
+                L.call("ydl_softmax_bwd", x.dt, _p(lazy.low), _p(dlow), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C,
+                       1, 1, _stream())
+                return
+            # pred had other consumers besides the loss: fold the summed part into one replica of the dense gradient
+            dp = dp.float().contiguous().clone()
+            dp.view(x.N, x.C, x.H, x.rep[0], x.W, x.rep[1])[:, :, :, 0, :, 0] += dlow
+        if dp.dtype != torch.float32 or dp.stride() != p.stride():
+            dp = dp.float().contiguous()
         sn, sc, sh, sw = p.stride()
         L.call("ydl_softmax_bwd", x.dt, _p(p), _p(dp), sn, sc, sh, sw, _p(gx), x.ld, x.N, x.H, x.W, x.C, x.rep[0], x.rep[1],
                _stream())
