@@ -53,18 +53,22 @@ typedef struct {
     int Ho, Wo, Cout;         /* output */
     int k, s, p;
     int ldx, ldy;             /* pixel strides of x and y (elements) */
+    int ldw;                  /* row stride (elements) of w in conv_fwd and of dw in conv_wgrad; 0 = dense = k*k*Cin_p.
+                                 A larger stride addresses a COLUMN BLOCK of a wider 1x1 weight matrix: a convolution
+                                 over a channel concat is evaluated as the sum of one convolution per source */
 } ydl_conv_geom;
 
 /* BN-statistics workspace of the forward epilogue: [grid_m][2][round_up(Cout,8)] floats, where block b of
  * the launch covered min(block_m, N*Ho*Wo - b*block_m) pixels.  The three queries are pure functions of g. */
 int64_t ydl_conv_fwd_stats_ws_bytes(const ydl_conv_geom* g, int dtype);
-int ydl_conv_fwd_grid_m(const ydl_conv_geom* g);
-int ydl_conv_fwd_block_m(const ydl_conv_geom* g);
+int ydl_conv_fwd_grid_m(const ydl_conv_geom* g, int dtype);
+int ydl_conv_fwd_block_m(const ydl_conv_geom* g, int dtype);
 
-/* y = conv(x, w).  If stats_ws != NULL the epilogue also writes per-block (sum, M2) partials of y per output
- * channel (from the f32 accumulators) for train-mode BN; finish them with ydl_bn_finalize. */
+/* y (+)= conv(x, w).  If stats_ws != NULL the epilogue also writes per-block (sum, M2) partials of the values it
+ * stores (f32 accumulators, plus the previous contents of y when accumulate != 0) per output channel for train-mode
+ * BN; finish them with ydl_bn_finalize. */
 int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
-                 float* stats_ws, void* stream);
+                 float* stats_ws, int accumulate, void* stream);
 /* dx (+)= conv_transpose(dy, wt).  accumulate != 0 adds into dx (gradient fan-in). */
 int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
                    int accumulate, void* stream);

@@ -40,8 +40,8 @@ def test_ctypes_table_matches_header():
 def test_error_path_without_gpu_call():
     """argument validation happens on the host before any launch: a bad geometry returns an error string"""
     from yolo_dual_amd import _lib as L
-    g = L.ConvGeom(1, 8, 8, 8, 9, 9, 8, 3, 1, 1, 8, 8)     # wrong Ho/Wo
-    rc = L.lib().ydl_conv_fwd(ctypes.byref(g), 0, None, None, None, None, None)
+    g = L.ConvGeom(1, 8, 8, 8, 9, 9, 8, 3, 1, 1, 8, 8, 0)     # wrong Ho/Wo
+    rc = L.lib().ydl_conv_fwd(ctypes.byref(g), 0, None, None, None, None, 0, None)
     assert rc != 0
     assert b"output size" in L.lib().ydl_last_error()
     assert L.lib().ydl_version() >= 1

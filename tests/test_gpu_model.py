@@ -8,7 +8,7 @@ import torch
 import yaml
 
 from oracle.fill import fill_state_dict
-from tests.util import Golden, rel_err
+from tests.util import Golden, l2_err, rel_err
 
 pytestmark = pytest.mark.gpu
 CW = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
@@ -147,6 +147,103 @@ def test_wgrad_transposed_read_matches_scalar_read(shape):
     assert rel_err(res[0].cpu(), res[1].cpu()) < 1e-4       # same products, different split-K / atomic order only
 
 
+@pytest.mark.parametrize("mode,c1,c2", [("bf16", 64, 64), ("bf16", 128, 128), ("bf16", 64, 128), ("bf16", 256, 256),
+                                        ("bf16", 128, 256), ("bf16", 256, 64), ("f32", 32, 64), ("f32", 64, 128),
+                                        ("f32", 128, 128), ("f32", 128, 256)])
+def test_pointwise_streaming_kernel_matches_tiled_kernel(mode, c1, c2):
+    """A/B the weight-stationary streaming kernel (1x1 convs, K row <= 512 B, M >= 65536 pixels; forward with BN partials
+    and dgrad) against the tiled implicit-GEMM kernel on a ragged pixel count: same products, different summation order."""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    ydl.set_compute_dtype(mode)
+    res = []
+    for pw in (1, 0):
+        L.lib().ydl_debug_set(1, pw)
+        torch.manual_seed(1)
+        m = ydl.Conv(c1, c2, 1, 1).cuda().train()
+        with torch.no_grad():
+            m.conv.weight.normal_(0, 0.1)
+            m.bn.weight.uniform_(0.5, 1.5)
+            m.bn.bias.normal_(0, 0.2)
+        x = (torch.randn(2, c1, 200, 173, device="cuda", generator=torch.Generator("cuda").manual_seed(2)) + 0.3).requires_grad_(True)
+        out = m(x)
+        (out * torch.randn(out.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(3))).sum().backward()
+        res.append([t.detach().float().cpu() for t in (out, x.grad, m.bn.running_mean, m.bn.running_var, m.conv.weight.grad,
+                                                        m.bn.weight.grad)])
+    L.lib().ydl_debug_set(1, 1)
+    tol = 1e-5 if mode == "f32" else 2e-2        # bf16: the two kernels round the same f32 sums, but BN statistics
+    names_ = ("out", "dx", "running_mean", "running_var", "dw", "dgamma")    # differing in the last bit move bf16 outputs
+    for a, b, nm in zip(res[0], res[1], names_):
+        assert l2_err(a, b) < tol, (nm, l2_err(a, b))
+    assert l2_err(res[0][2], res[1][2]) < 1e-5 and l2_err(res[0][3], res[1][3]) < 1e-5     # statistics come from f32 accumulators
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_pointwise_streaming_kernel_in_c3_block(mode):
+    """the same A/B through a C3 block: fused cv1|cv2 pair writing channel slices (ld != C), dgrad accumulation into a shared
+    input gradient"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    ydl.set_compute_dtype(mode)
+    c = 64 if mode == "f32" else 128
+    res = []
+    for pw in (1, 0):
+        L.lib().ydl_debug_set(1, pw)
+        torch.manual_seed(4)
+        m = ydl.C3(c, c, 1).cuda().train()
+        x = torch.randn(2, c, 184, 180, device="cuda", generator=torch.Generator("cuda").manual_seed(5)).requires_grad_(True)
+        out = m(x)
+        (out * torch.randn(out.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(6))).sum().backward()
+        res.append([out.detach().float().cpu(), x.grad.float().cpu()] + [p.grad.float().cpu().flatten() for p in m.parameters()])
+    L.lib().ydl_debug_set(1, 1)
+    tol = 2e-5 if mode == "f32" else 5e-2
+    for a, b in zip(res[0], res[1]):
+        assert l2_err(a, b) < tol, l2_err(a, b)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_commuted_concat_conv_matches_materialised_concat(mode):
+    """conv1x1(cat(a, bilinear_up(b))) evaluated as conv_a(a) + bilinear_up(conv_b(b)) (virtual concat, column-block weight
+    gradients) == the plain path (resize b, concat, one conv) on the whole yolov5 model: prediction, loss, every gradient."""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
+    ydl.set_compute_dtype(mode)
+    cfg = _cfg("yolov5_seg.yaml", {"C3_DCN": "C3"})
+    res = []
+    for on in (True, False):
+        config.set_commute_concat(on)
+        try:
+            m = ydl.YOLOv5Seg(cfg)
+            m.img_size = [128, 128]
+            sd = m.state_dict()
+            fill_state_dict(sd, 5)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.9, weight_decay=0.0)
+            crit = ydl.SegmentationLoss(12, 0.0, CW, "dice", sync=False)
+            gen = torch.Generator("cuda").manual_seed(0)
+            x = torch.rand(2, 3, 128, 128, device="cuda", generator=gen)
+            t = torch.randint(0, 12, (2, 128, 128), device="cuda", generator=gen)
+            opt.zero_grad()
+            out = m(x)
+            total, _ = crit(out, t)
+            total.backward()
+            named = dict(m.named_parameters())
+            grads = {k: p.grad.detach().float().cpu().clone() for k, p in named.items() if getattr(p, "_ydl_touched", False)}
+            res.append((out.detach().cpu(), float(total), grads,
+                        {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if "running" in k}))
+        finally:
+            config.set_commute_concat(True)
+    (o1, l1, g1, r1), (o0, l0, g0, r0) = res
+    assert sorted(g1) == sorted(g0)                       # same dead-parameter set
+    to, tg = (1e-5, 2e-4) if mode == "f32" else (3e-2, 0.15)
+    assert l2_err(o1, o0) < to and abs(l1 - l0) <= to * abs(l0)
+    for k in r0:
+        assert l2_err(r1[k], r0[k]) < to, k
+    bad = {k: l2_err(g1[k], g0[k]) for k in g0 if l2_err(g1[k], g0[k]) >= tg}
+    assert not bad, bad
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (bs=16 would need ~10 GB of activations; bs=4 keeps the test quick): size-independent
     checks — probabilities sum to 1, finite loss, every live parameter gets a finite non-zero gradient, and the
@@ -221,5 +318,7 @@ def test_graph_capture_matches_eager():
             assert nbt == 6, nbt
             assert opt.updates == 6
         losses[mode] = rec
+    # same kernels on the same data in the same order: the replayed trajectory is the eager one to the last bit of the
+    # printed loss (a 2e-2 tolerance here once hid a replay that ran with broken cross-stream ordering)
     for a, b in zip(losses["eager"][2:], losses["graph"][2:]):
-        assert abs(a - b) <= 2e-2 * abs(a), (losses)
+        assert abs(a - b) <= 1e-6 * abs(a), (losses)

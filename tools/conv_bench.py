@@ -15,7 +15,8 @@ from yolo_dual_amd import _lib as L
 LAYERS = [(3, 64, 6, 2, 320), (64, 128, 3, 2, 160), (128, 64, 1, 1, 160), (64, 64, 3, 1, 160), (128, 128, 1, 1, 160),
           (128, 256, 3, 2, 80), (256, 128, 1, 1, 80), (128, 128, 3, 1, 80), (256, 256, 1, 1, 80), (256, 512, 3, 2, 40),
           (256, 256, 3, 1, 40), (512, 512, 1, 1, 40), (512, 1024, 3, 2, 20), (512, 512, 3, 1, 20), (2048, 1024, 1, 1, 20),
-          (640, 64, 1, 1, 160), (128, 64, 3, 1, 160), (768, 128, 1, 1, 80), (64, 12, 1, 1, 160)]
+          (640, 64, 1, 1, 160), (128, 64, 3, 1, 160), (768, 128, 1, 1, 80), (64, 12, 1, 1, 160),
+          (64, 64, 1, 1, 160), (64, 128, 1, 1, 160), (128, 256, 1, 1, 80), (256, 64, 1, 1, 80), (512, 128, 1, 1, 40)]
 
 
 def main():
@@ -27,8 +28,12 @@ def main():
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--nostats", action="store_true")
     ap.add_argument("--wg", type=int, default=1)
+    ap.add_argument("--pw", type=int, default=1, help="0: tiled kernel for the short-K 1x1 layers")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many tensor sets (defeats the 256 MB MALL)")
+    ap.add_argument("--acc", type=int, default=0, help="dgrad accumulate flag")
     a = ap.parse_args()
     L.lib().ydl_debug_set(0, a.wg)
+    L.lib().ydl_debug_set(1, a.pw)
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")
@@ -41,10 +46,11 @@ def main():
         Hi = Ho * s
         N = a.bs
         ldx, ldy = r8(Cin), r8(Cout)
-        x = torch.randn(N, Hi, Hi, ldx, device=dev).to(tdt)
-        y = torch.empty(N, Ho, Ho, ldy, device=dev, dtype=tdt)
-        dy = torch.randn(N, Ho, Ho, ldy, device=dev).to(tdt)
-        dx = torch.empty(N, Hi, Hi, ldx, device=dev, dtype=tdt)
+        R = a.rotate
+        xs = [torch.randn(N, Hi, Hi, ldx, device=dev).to(tdt) for _ in range(R)]
+        ys = [torch.empty(N, Ho, Ho, ldy, device=dev, dtype=tdt) for _ in range(R)]
+        dys = [torch.randn(N, Ho, Ho, ldy, device=dev).to(tdt) for _ in range(R)]
+        dxs = [torch.zeros(N, Hi, Hi, ldx, device=dev, dtype=tdt) for _ in range(R)]
         w = torch.randn(Cout, k * k, ldx, device=dev).to(tdt)
         wt = torch.randn(Cin, k * k, ldy, device=dev).to(tdt)
         dw = torch.zeros(Cout, k * k, ldx, device=dev, dtype=torch.float32)
@@ -54,19 +60,24 @@ def main():
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         flops = 2.0 * N * Ho * Ho * Cout * k * k * Cin
         byts = (N * Hi * Hi * Cin + N * Ho * Ho * Cout) * (2 if a.dtype == "bf16" else 4)
-        ops = {"fwd": lambda: L.call("ydl_conv_fwd", gp, dt, P(x), P(w), P(y), None if a.nostats else P(ws), st),
-               "dgrad": lambda: L.call("ydl_conv_dgrad", gp, dt, P(dy), P(wt), P(dx), 0, st),
-               "wgrad": lambda: L.call("ydl_conv_wgrad", gp, dt, P(x), P(dy), P(dw), st)}
+        it = [0]
+
+        def nxt():
+            it[0] += 1
+            return it[0] % R
+        ops = {"fwd": lambda i: L.call("ydl_conv_fwd", gp, dt, P(xs[i]), P(w), P(ys[i]), None if a.nostats else P(ws), 0, st),
+               "dgrad": lambda i: L.call("ydl_conv_dgrad", gp, dt, P(dys[i]), P(wt), P(dxs[i]), a.acc, st),
+               "wgrad": lambda i: L.call("ydl_conv_wgrad", gp, dt, P(xs[i]), P(dys[i]), P(dw), st)}
         line = f"[{li:2d}] {Cin:5d}->{Cout:5d} k{k}s{s} @{Ho:4d}"
         for name, fn in ops.items():
             if a.what not in ("all", name):
                 continue
             for _ in range(3):
-                fn()
+                fn(nxt())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                fn()
+                fn(nxt())
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters

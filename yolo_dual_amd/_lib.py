@@ -19,7 +19,7 @@ class ConvGeom(C.Structure):
     _fields_ = [("N", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Cin", C.c_int),
                 ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
                 ("k", C.c_int), ("s", C.c_int), ("p", C.c_int),
-                ("ldx", C.c_int), ("ldy", C.c_int)]
+                ("ldx", C.c_int), ("ldy", C.c_int), ("ldw", C.c_int)]
 
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -31,9 +31,9 @@ SIGNATURES = {
     "ydl_version": (_i, []),
     "ydl_debug_set": (None, [_i, _i]),
     "ydl_conv_fwd_stats_ws_bytes": (_i64, [_G, _i]),
-    "ydl_conv_fwd_grid_m": (_i, [_G]),
-    "ydl_conv_fwd_block_m": (_i, [_G]),
-    "ydl_conv_fwd": (_i, [_G, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ydl_conv_fwd_grid_m": (_i, [_G, _i]),
+    "ydl_conv_fwd_block_m": (_i, [_G, _i]),
+    "ydl_conv_fwd": (_i, [_G, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_dgrad": (_i, [_G, _i, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_wgrad": (_i, [_G, _i, _vp, _vp, _vp, _vp]),
     "ydl_weight_prep": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -129,8 +129,17 @@ def profile_end():
     return out
 
 
+_LAUNCHES = [0]
+
+
+def launch_count() -> int:
+    """number of entry-point calls so far (stream-fork bookkeeping: 'has anything been enqueued since ...')"""
+    return _LAUNCHES[0]
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise on error."""
+    _LAUNCHES[0] += 1
     if _PROFILE is None:
         check(getattr(lib(), name)(*args), name)
         return

@@ -1,7 +1,11 @@
 """Process-wide settings of the HIP path."""
 from __future__ import annotations
 
-_STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True, "fuse_siblings": True, "overlap_wgrad": True}
+import os
+
+_STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True, "fuse_siblings": True, "overlap_wgrad": os.environ.get("YDL_OVERLAP_WGRAD", "1") != "0",
+          "commute_concat": os.environ.get("YDL_COMMUTE_CONCAT", "1") != "0",
+          "replicated_loss": os.environ.get("YDL_REPLICATED_LOSS", "1") != "0"}
 
 
 def set_compute_dtype(name: str) -> None:
@@ -41,6 +45,21 @@ def overlap_wgrad() -> bool:
 
 def set_overlap_wgrad(on: bool) -> None:
     _STATE["overlap_wgrad"] = bool(on)
+
+
+def commute_concat() -> bool:
+    """conv1x1(cat(a, bilinear_up(b))) is evaluated as conv1x1_a(a) + bilinear_up(conv1x1_b(b)) (the wide low-resolution
+    source is never up-sampled)"""
+    return _STATE["commute_concat"]
+
+
+def set_commute_concat(on: bool) -> None:
+    _STATE["commute_concat"] = bool(on)
+
+
+def replicated_loss() -> bool:
+    """SegmentationLoss evaluates a nearest-replicated prediction per stored pixel (ydl_seg_loss_rep_*)"""
+    return _STATE["replicated_loss"]
 
 
 def weight_epoch() -> int:

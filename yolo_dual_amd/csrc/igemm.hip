@@ -37,6 +37,7 @@ struct IgemmArgs {
     int M;            // N*Hg*Wg
     int stats_ld;
     unsigned bytesA, bytesB;   // buffer extents for the range-checked loads
+    unsigned ldb_bytes;        // byte stride between weight rows (Ttot*Kc*ES when dense)
     int grid_n;                // number of output-channel tiles (the grid is 1-D: grid_m * grid_n)
     signed char dh[MAXTAPS], dw[MAXTAPS];
     unsigned char wt[MAXTAPS];
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         int row = r + RPP * i;
         int co = n0 + row;
         bvalid[i] = row < BN && co < p.Cout;
-        browoff[i] = (unsigned)co * (unsigned)(p.Ttot * p.Kc * ES);
+        browoff[i] = (unsigned)co * p.ldb_bytes;
     }
     const int cpt = p.Kc / V;                       // chunks per tap
     const int nchunks = p.ntaps * cpt;
@@ -298,12 +299,13 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
                         u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
                         *d2 = u;
                     }
+                    if (p.accumulate) acc[c][j] = f32x4{v[0], v[1], v[2], v[3]};     // the statistics below see the sums
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (co + e < p.Cst) {
                             float v = acc[c][j][e];
-                            if (p.accumulate) v += ET<T>::ld(dst + co + e);
+                            if (p.accumulate) { v += ET<T>::ld(dst + co + e); acc[c][j][e] = v; }
                             ET<T>::st(dst + co + e, v);
                         }
                 }
@@ -379,6 +381,274 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Point-wise (1x1, stride 1) convolutions with a short K (row = 128..512 bytes of K) on large pixel counts.
+// These layers are HBM-bound (2 bytes in + 2 bytes out per MAC row) and the tiled kernel above runs them at ~45 % of
+// the HBM rate: with 2..4 K-steps a CTA is three dependent memory round trips (load, load, store) and two CTAs per CU
+// cannot cover them.  This kernel streams instead:
+//   * weight-stationary: the whole [Cout][K] weight matrix is copied to LDS once per CTA (XOR-swizzled 16-byte chunks,
+//     conflict-free ds_read_b128 fragments), CTAs are persistent over a CONTIGUOUS range of block_m pixels;
+//   * activations never touch LDS: a lane loads its MFMA B-operand chunks (pixel = lane & 15, 16 bytes of K per lane
+//     group) straight from global memory, NB pixel tiles in flight per wave => no barrier in the main loop;
+//   * a wave owns 16 pixels x (CT*16) output channels per step: stores 8/16 B per lane into the NHWC rows;
+//   * BN partials: per-lane (count, sum, sum of squares) over the wave's few tiles (n <= block_m/(16*WP): no
+//     cancellation at that size), converted to (mean, M2) and Chan-merged over the 16 pixel lanes with the transposing
+//     butterfly, then over the CTA's pixel waves through LDS => the same [grid_m][2][C] (sum, M2) contract.
+// ------------------------------------------------------------------------------------------------------
+struct PwArgs {
+    const void* X; const void* W; void* Y; float* stats;
+    int M, lda, ldc, Cout, WN, accumulate, block_m, stats_ld;
+    unsigned bytesX, ldw_bytes;
+};
+
+template <typename T, int RB, int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
+    constexpr int ES = sizeof(T);
+    constexpr int J = RB / 64;                  // fragment groups per K row (each = 4 lane-group chunks of 16 B)
+    constexpr int CPR = RB / 16;                // chunks per row
+    constexpr int NB = (J >= 8) ? 3 : 4;        // pixel tiles in flight per wave (register budget)
+    constexpr int NV = CT * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                                      // [Cout][RB], chunk q of row r at slot q ^ sw(r)
+    float* sred = (float*)(smem + (size_t)p.Cout * RB);            // [WP][Cout][2] (mean, M2) + [WP] counts
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int WN = p.WN, WP = NW / WN;
+    const int wc = wave % WN, wp = wave / WN;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int m_begin = blockIdx.x * p.block_m;
+    const int m_end = min(p.M, m_begin + p.block_m);
+    const int ntiles = (m_end - m_begin + 15) >> 4;
+    const int nsteps = (ntiles + WP - 1) / WP;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.bytesX, 0x00020000);
+    const unsigned rowbytes = (unsigned)(p.lda * ES);
+
+    uint4 bq[NB][J];
+    auto load = [&](int i, uint4 (&b)[J]) {
+        const int m = m_begin + ((i * WP + wp) << 4) + lrow;
+        const bool ok = m < m_end;
+        const unsigned base = (unsigned)m * rowbytes + (unsigned)(lgrp << 4);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? base + j * 64 : 0xFFFFFFFFu, 0, 0);
+            b[j] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+        if (u < nsteps) load(u, bq[u]);
+
+    for (int i = t; i < p.Cout * CPR; i += NW * 64) {
+        const int r = i / CPR, q = i & (CPR - 1);
+        const uint4 v = *(const uint4*)((const unsigned char*)p.W + (size_t)r * p.ldw_bytes + (q << 4));
+        const int sw = CPR == 8 ? (r >> 1) & 7 : r & 15;
+        *(uint4*)(sW + r * RB + ((q ^ sw) << 4)) = v;
+    }
+    __syncthreads();
+
+    const int co0 = wc * CT * 16;
+    const unsigned char* const wbase = sW + (co0 + lrow) * RB;
+    const int swr = CPR == 8 ? (lrow >> 1) & 7 : lrow;
+    T* const Yg = (T*)p.Y;
+    float s1[NV], s2[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { s1[v] = 0.f; s2[v] = 0.f; }
+    float cnt = 0.f;
+    const bool want_stats = p.stats != nullptr;
+
+    for (int i0 = 0; i0 < nsteps; i0 += NB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = i0 + u;
+            if (i < nsteps) {
+                // the weight fragments are re-read from LDS every step: without this fence the compiler hoists all
+                // J*CT loop-invariant ds_reads into registers (+128 VGPRs => one wave per SIMD, or spills)
+                asm volatile("" ::: "memory");
+                f32x4 acc[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int koff = (((j << 2) | lgrp) ^ swr) << 4;
+                    uint4 af[CT];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(wbase + c * 16 * RB + koff);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) Mma<T>::run(af[c], bq[u][j], acc[c]);
+                }
+                if (i + NB < nsteps) load(i + NB, bq[u]);
+                const int m = m_begin + ((i * WP + wp) << 4) + lrow;
+                if (m < m_end) {
+                    T* dst = Yg + (size_t)m * p.ldc + co0 + lgrp * 4;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        float v[4] = {acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+                        if constexpr (sizeof(T) == 4) {
+                            float4* d4 = (float4*)(dst + c * 16);
+                            if (p.accumulate) { float4 o = *d4; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                            *d4 = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            uint2* d2 = (uint2*)(dst + c * 16);
+                            if (p.accumulate) {
+                                uint2 o = *d2;
+                                v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+                                v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+                            }
+                            uint2 w2;
+                            w2.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                            w2.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                            *d2 = w2;
+                        }
+                        if (want_stats) {       // statistics of the stored f32 values (including an accumulated y)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                s1[c * 4 + e] += v[e];
+                                s2[c * 4 + e] = fmaf(v[e], v[e], s2[c * 4 + e]);
+                            }
+                        }
+                    }
+                    if (want_stats) cnt += 1.f;
+                }
+            }
+        }
+    }
+
+    if (want_stats) {
+        // per-lane (count, mean, M2), then Chan-merge over the 16 pixel lanes: stage s pairs lanes that differ in bit s;
+        // the lane whose bit is 0 keeps the even-indexed aggregates, its partner the odd ones (live values halve).
+        float mean[NV], m2[NV];
+        {
+            const float rn = cnt > 0.f ? 1.f / cnt : 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                mean[v] = s1[v] * rn;
+                m2[v] = fmaxf(s2[v] - s1[v] * mean[v], 0.f);
+            }
+        }
+        int live = NV;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int mask = 1 << s;
+            const bool hi = (lrow >> s) & 1;
+            const float cnt_o = __shfl_xor(cnt, mask, 64);
+            const float tot = cnt + cnt_o;
+            const float rt = tot > 0.f ? 1.f / tot : 0.f;
+            const float fo = cnt_o * rt, fx = cnt * cnt_o * rt;
+            if (live > 1) {
+#pragma unroll
+                for (int k = 0; k < NV / 2; ++k)
+                    if (k < live / 2) {
+                        const float km = hi ? mean[2 * k + 1] : mean[2 * k], sm = hi ? mean[2 * k] : mean[2 * k + 1];
+                        const float kq = hi ? m2[2 * k + 1] : m2[2 * k], sq = hi ? m2[2 * k] : m2[2 * k + 1];
+                        const float om = __shfl_xor(sm, mask, 64), oq = __shfl_xor(sq, mask, 64);
+                        const float d = om - km;
+                        mean[k] = km + d * fo;
+                        m2[k] = kq + oq + d * d * fx;
+                    }
+                live >>= 1;
+            } else {
+                const float om = __shfl_xor(mean[0], mask, 64), oq = __shfl_xor(m2[0], mask, 64);
+                const float d = om - mean[0];
+                mean[0] = mean[0] + d * fo;
+                m2[0] = m2[0] + oq + d * d * fx;
+            }
+            cnt = tot;
+        }
+        // slot tt of lane lrow now holds value index (tt << 4 | lrow)  (NV >= 16), channel = co0 + (idx>>2)*16 + lgrp*4 + (idx&3)
+        float* scnt = sred + (size_t)WP * p.Cout * 2;
+#pragma unroll
+        for (int tt = 0; tt < NV / 16; ++tt) {
+            const int idx = (tt << 4) | lrow;
+            const int ch = co0 + (idx >> 2) * 16 + lgrp * 4 + (idx & 3);
+            sred[((size_t)wp * p.Cout + ch) * 2] = mean[tt];
+            sred[((size_t)wp * p.Cout + ch) * 2 + 1] = m2[tt];
+        }
+        if (lane == 0 && wc == 0) scnt[wp] = cnt;
+        __syncthreads();
+        for (int ch = t; ch < p.Cout; ch += NW * 64) {
+            float n = 0.f, mu = 0.f, q2 = 0.f;
+            for (int w = 0; w < WP; ++w) {
+                const float nb = scnt[w];
+                const float mb = sred[((size_t)w * p.Cout + ch) * 2], qb = sred[((size_t)w * p.Cout + ch) * 2 + 1];
+                const float tot = n + nb;
+                const float rt = tot > 0.f ? 1.f / tot : 0.f;
+                const float d = mb - mu;
+                mu = mu + d * nb * rt;
+                q2 = q2 + qb + d * d * n * nb * rt;
+                n = tot;
+            }
+            float* dst = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld;
+            dst[ch] = mu * n;
+            dst[p.stats_ld + ch] = q2;
+        }
+    }
+}
+
+struct PwPlan { bool ok; int RB, CT, WN, NW, block_m, grid_m; size_t smem; };
+static int g_pw_enabled = 1;
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return cus;
+}
+// eligibility + launch geometry; a pure function of its arguments (the stats-workspace queries call it too)
+static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) {
+    PwPlan pl{};
+    pl.ok = false;
+    if (!g_pw_enabled || !pointwise || Cst != Cout || M < 65536) return pl;
+    const int RB = Kc * es;
+    if (RB != 128 && RB != 256 && RB != 512) return pl;
+    if (Cout != 64 && Cout != 128 && Cout != 256) return pl;
+    const long wbytes = (long)Cout * RB;
+    if (wbytes > 128 * 1024) return pl;
+    pl.RB = RB;
+    pl.CT = Cout >= 128 ? 8 : 4;
+    pl.WN = Cout / (pl.CT * 16);
+    // 512-byte rows x 128+ channels need ~230 VGPRs: as 4-wave CTAs that is one wave per SIMD; one 8-wave CTA per CU
+    // gives two
+    pl.NW = (RB == 512 && pl.CT == 8) ? 8 : 4;
+    const int slots = device_cus() * (pl.NW == 4 ? 2 : 1);
+    int bm = round_up((M + slots - 1) / slots, 16);
+    pl.block_m = bm;
+    pl.grid_m = (M + bm - 1) / bm;
+    const int WP = pl.NW / pl.WN;
+    pl.smem = (size_t)wbytes + (size_t)WP * Cout * 2 * sizeof(float) + 64;
+    pl.ok = true;
+    return pl;
+}
+
+template <typename T, int RB, int CT, int NW>
+static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pw_kernel<T, RB, CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        attr_set = true;
+    }
+    pw_kernel<T, RB, CT, NW><<<pl.grid_m, NW * 64, pl.smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int launch_pw(const PwArgs& a, const PwPlan& pl, hipStream_t st) {
+    if (pl.NW == 8) {
+        YDL_CHECK(pl.RB == 512 && pl.CT == 8, "internal: unexpected point-wise plan");
+        return launch_pw_cfg<T, 512, 8, 8>(a, pl, st);
+    }
+    if (pl.RB == 128) return pl.CT == 8 ? launch_pw_cfg<T, 128, 8, 4>(a, pl, st) : launch_pw_cfg<T, 128, 4, 4>(a, pl, st);
+    if (pl.RB == 256) return pl.CT == 8 ? launch_pw_cfg<T, 256, 8, 4>(a, pl, st) : launch_pw_cfg<T, 256, 4, 4>(a, pl, st);
+    YDL_CHECK(pl.CT == 4, "internal: unexpected point-wise plan");
+    return launch_pw_cfg<T, 512, 4, 4>(a, pl, st);
+}
+
+static bool args_pointwise(const IgemmArgs& a) {
+    return a.ntaps == 1 && a.Ttot == 1 && a.dh[0] == 0 && a.dw[0] == 0 && a.in_mul == 1 && a.out_mul == 1 && a.out_h0 == 0 &&
+           a.out_w0 == 0 && a.Hg == a.Ho && a.Wg == a.Wo && a.Hi == a.Ho && a.Wi == a.Wo;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int NW = 4>
@@ -413,6 +683,17 @@ static TileCfg pick_cfg(int M, int Cst) {
 
 template <typename T>
 static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = nullptr, int force_bm = 0) {
+    {
+        const PwPlan pl = pw_plan(a.M, a.Kc, a.Cout, a.Cst, (int)sizeof(T), args_pointwise(a));
+        if (pl.ok && !force_bm) {
+            PwArgs q{};
+            q.X = a.A; q.W = a.B; q.Y = a.C; q.stats = a.stats;
+            q.M = a.M; q.lda = a.lda; q.ldc = a.ldc; q.Cout = a.Cout; q.WN = pl.WN; q.accumulate = a.accumulate;
+            q.block_m = pl.block_m; q.stats_ld = a.stats_ld; q.bytesX = a.bytesA; q.ldw_bytes = a.ldb_bytes;
+            if (grid_m_out) *grid_m_out = pl.grid_m;
+            return launch_pw<T>(q, pl, st);
+        }
+    }
     TileCfg c = pick_cfg(a.M, a.Cst);
     if (force_bm) c.BM = force_bm;
     if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
@@ -429,7 +710,8 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = 
 static int set_extents(IgemmArgs& a, int dtype) {
     const unsigned long long es = (unsigned long long)esize(dtype);
     unsigned long long ba = (unsigned long long)a.N * a.Hi * a.Wi * a.lda * es;
-    unsigned long long bb = (unsigned long long)a.Cout * a.Ttot * a.Kc * es;
+    if (a.ldb_bytes == 0) a.ldb_bytes = (unsigned)((unsigned long long)a.Ttot * a.Kc * es);
+    unsigned long long bb = (unsigned long long)(a.Cout - 1) * a.ldb_bytes + (unsigned long long)a.Ttot * a.Kc * es;
     YDL_CHECK(ba < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "tensor larger than 4 GiB: not addressable by the 32-bit buffer loads");
     a.bytesA = (unsigned)ba;
     a.bytesB = (unsigned)bb;
@@ -447,32 +729,33 @@ static int check_geom(const ydl_conv_geom* g, int dtype) {
     YDL_CHECK(g->ldx >= round_up(g->Cin, 8) && g->ldy >= g->Cout, "pixel stride smaller than channel count");
     YDL_CHECK((g->ldx * es) % 16 == 0 && (g->ldy * es) % 16 == 0, "pixel strides must be 16-byte multiples");
     YDL_CHECK((int64_t)g->N * g->Hi * g->Wi < (1ll << 31) && (int64_t)g->N * g->Ho * g->Wo < (1ll << 31), "too many pixels");
+    YDL_CHECK(g->ldw == 0 || (g->ldw >= g->k * g->k * round_up(g->Cin, 8) && (g->ldw * es) % 16 == 0),
+              "ldw must be 0 (dense) or a 16-byte-multiple row stride >= k*k*round_up(Cin, 8)");
     return 0;
 }
 
-// number of M-blocks the forward launch will use (needed by the caller to size/consume the stats partials)
-static int fwd_grid_m(const ydl_conv_geom* g) {
+// number of M-blocks / pixels per block of the forward launch (the caller sizes and consumes the stats partials with them)
+static void fwd_blocks(const ydl_conv_geom* g, int dtype, int* grid_m, int* block_m) {
     int M = g->N * g->Ho * g->Wo;
     int Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
+    const PwPlan pl = pw_plan(M, round_up(g->Cin, 8), g->Cout, Cst, esize(dtype), g->k == 1 && g->s == 1 && g->p == 0);
+    if (pl.ok) { *grid_m = pl.grid_m; *block_m = pl.block_m; return; }
     TileCfg c = pick_cfg(M, Cst);
-    return (M + c.BM - 1) / c.BM;
+    *grid_m = (M + c.BM - 1) / c.BM;
+    *block_m = c.BM;
 }
 
 extern "C" int64_t ydl_conv_fwd_stats_ws_bytes(const ydl_conv_geom* g, int dtype) {
-    (void)dtype;
     // [gridM][2][round_up(Cout,8)] floats + room for ydl_bn_finalize's level-1 chunk partials (gridM/64 + 1 rows)
-    int64_t gm = fwd_grid_m(g);
-    return (gm + gm / 64 + 2) * 2 * round_up(g->Cout, 8) * (int64_t)sizeof(float);
+    int gm, bm;
+    fwd_blocks(g, dtype, &gm, &bm);
+    return ((int64_t)gm + gm / 64 + 2) * 2 * round_up(g->Cout, 8) * (int64_t)sizeof(float);
 }
-extern "C" int ydl_conv_fwd_grid_m(const ydl_conv_geom* g) { return fwd_grid_m(g); }
-extern "C" int ydl_conv_fwd_block_m(const ydl_conv_geom* g) {
-    int M = g->N * g->Ho * g->Wo;
-    int Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
-    return pick_cfg(M, Cst).BM;
-}
+extern "C" int ydl_conv_fwd_grid_m(const ydl_conv_geom* g, int dtype) { int gm, bm; fwd_blocks(g, dtype, &gm, &bm); return gm; }
+extern "C" int ydl_conv_fwd_block_m(const ydl_conv_geom* g, int dtype) { int gm, bm; fwd_blocks(g, dtype, &gm, &bm); return bm; }
 
 extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
-                            float* stats_ws, void* stream) {
+                            float* stats_ws, int accumulate, void* stream) {
     if (int e = check_geom(g, dtype)) return e;
     YDL_CHECK(aligned16(x) && aligned16(w) && aligned16(y), "pointers must be 16-byte aligned");
     IgemmArgs a{};
@@ -482,9 +765,10 @@ extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, co
     a.Ho = g->Ho; a.Wo = g->Wo; a.ldc = g->ldy; a.Cout = g->Cout;
     a.Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
     a.Hg = g->Ho; a.Wg = g->Wo; a.in_mul = g->s; a.out_mul = 1; a.out_h0 = 0; a.out_w0 = 0;
-    a.ntaps = g->k * g->k; a.Ttot = a.ntaps; a.accumulate = 0;
+    a.ntaps = g->k * g->k; a.Ttot = a.ntaps; a.accumulate = accumulate ? 1 : 0;
     a.M = g->N * g->Ho * g->Wo;
     a.stats_ld = round_up(g->Cout, 8);
+    a.ldb_bytes = (unsigned)(g->ldw * esize(dtype));
     for (int r = 0; r < g->k; ++r)
         for (int s = 0; s < g->k; ++s) {
             int tpi = r * g->k + s;
@@ -558,6 +842,7 @@ struct WgradArgs {
     unsigned long long magicW, magicHW;   // ceil(2^40 / Wo), ceil(2^40 / (Ho*Wo)): division-free pixel decode
     unsigned bytesX, bytesY;
     int njt, nct;                 // tile counts (1-D grid = njt * nct * splits)
+    int ldw;                      // dW row stride (floats)
 };
 
 __device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
@@ -723,7 +1008,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int co = ct * TE + wi * SUB + a * 16 + (lane >> 4) * 4 + e;
-                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * wrow + j, acc[a][b][e]);
+                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
                 }
             }
         }
@@ -750,6 +1035,7 @@ struct Wgrad2Args {
     unsigned long long magicW, magicHW;   // ceil(2^40 / Wo), ceil(2^40 / (Ho*Wo))
     unsigned bytesX, bytesY;
     int njt, nct;
+    int ldw;                              // dW row stride (floats)
 };
 
 template <int TCO>
@@ -873,7 +1159,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int co = ct * TCO + wi * 64 + a * 16 + (lane >> 4) * 4 + e;
-                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * wrow + j, acc[a][b][e]);
+                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
                 }
             }
         }
@@ -885,6 +1171,7 @@ static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, 
     a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = round_up(g->Cin, 8);
     a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
     a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = g->k * g->k;
+    a.ldw = g->ldw ? g->ldw : a.ntaps * a.Kc;
     a.M = g->N * g->Ho * g->Wo;
     unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * 2ull;
     unsigned long long by = (unsigned long long)a.M * g->ldy * 2ull;
@@ -922,7 +1209,11 @@ static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, 
 
 static int g_wgrad_tr = 1;
 // debug knobs: key 0 = bf16 wgrad path: 1 (default) 128-wide tr-read kernel, 2 64x64 tr-read kernel, 0 64x64 scalar-LDS-read kernel
-extern "C" void ydl_debug_set(int key, int val) { if (key == 0) g_wgrad_tr = val; }
+//              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
+extern "C" void ydl_debug_set(int key, int val) {
+    if (key == 0) g_wgrad_tr = val;
+    if (key == 1) g_pw_enabled = val;
+}
 
 extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream) {
     if (int e = check_geom(g, dtype)) return e;
@@ -934,6 +1225,7 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = round_up(g->Cin, 8);
     a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
     a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = g->k * g->k;
+    a.ldw = g->ldw ? g->ldw : a.ntaps * a.Kc;
     a.M = g->N * g->Ho * g->Wo;
     {
         unsigned long long es = (unsigned long long)esize(dtype);

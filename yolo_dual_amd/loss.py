@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import config
 from .tape import _p, _stream
 
 
@@ -87,7 +88,7 @@ class SegmentationLoss(nn.Module):
         self.label_smoothing = float(label_smoothing)
         self.kind = {"dice": L.LOSS_DICE, "jaccard": L.LOSS_JACCARD}[kind]
         self.sync = sync
-        self.use_replicated = True       # False forces the full-resolution kernels (tests compare the two)
+        self.use_replicated = config.replicated_loss()   # False forces the full-resolution kernels (tests compare the two)
         self.class_weights = None if class_weights is None else torch.as_tensor(class_weights, dtype=torch.float32)
 
     def forward(self, pred: torch.Tensor, target: torch.Tensor) -> Tuple[torch.Tensor, List[float]]:

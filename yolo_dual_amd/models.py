@@ -180,10 +180,16 @@ class _YamlSegModel(YdlModule):
         use_side = bool(self._dead_head) and _cfg.overlap_wgrad()
         main = torch.cuda.current_stream()
         side = side_stream(tape.device) if use_side else None
+        fork_mark = -1                   # launch counter at the last fork: nothing new to wait for if unchanged
         for i, (layer, (from_, _num, _module, _args)) in enumerate(zip(self.head, self.yaml["head"])):
             inp = [outs[f] for f in from_] if isinstance(from_, list) else outs[from_]
             if use_side and i in self._dead_head:
-                side.wait_stream(main)                      # inputs come from layers already enqueued on main
+                # inputs come from layers already enqueued on main: one fork per RUN of consecutive dead layers.
+                # (A fork per layer put two event waits back to back on the side stream whenever a dead layer launched
+                # nothing — a virtual concat — and the captured HIP graph then replayed with broken ordering.)
+                if (i == 0 or (i - 1) not in self._dead_head) and L.launch_count() != fork_mark:
+                    side.wait_stream(main)
+                    fork_mark = L.launch_count()
                 with torch.cuda.stream(side):
                     outs.append(layer._fwd(tape, inp) if not isinstance(layer, Softmax) else tape.softmax(inp))
                 tape._side_fwd = True

@@ -11,6 +11,8 @@ Every module accepts either a tape ``Var`` (inside a model: one taped region for
 """
 from __future__ import annotations
 
+import ctypes
+
 import math
 from typing import List, Optional, Sequence, Union
 
@@ -257,16 +259,24 @@ class Conv(YdlModule):
         config.mark_touched(self.bn.weight)
         config.mark_touched(self.bn.bias)
 
-    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
+    def splittable(self) -> bool:
+        """the weight gradient can be written per input-channel block (``wgrad(col0=...)``): dense KRSC storage"""
+        return self.c1 % 8 == 0 and self.conv.weight.detach().permute(0, 2, 3, 1).is_contiguous()
+
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True) -> None:
+        """``col0``: first input channel of the block this call covers (gp.ldw = total padded Cin then); ``final``: the
+        last launch writing this parameter's gradient (only then may the data-parallel hook see it)"""
         p = self.conv.weight
         g = self._grad_of(p)
         gk = g.permute(0, 2, 3, 1)
         kk = self.k * self.k
         cin_p = round_up(self.c1, 8)
         if cin_p == self.c1 and gk.is_contiguous():
-            L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(gk), st)
-            config.mark_touched(p)
+            L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
+            if final:
+                config.mark_touched(p)
             return
+        assert col0 == 0 and final
         tmp = torch.zeros((self.c2, kk, cin_p), dtype=torch.float32, device=g.device)
         L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(tmp), st)
         if gk.is_contiguous():
@@ -381,12 +391,16 @@ class _FusedPair:
             for p in self._grads(which):
                 config.mark_touched(p)
 
-    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
+    def splittable(self) -> bool:
+        return self.c1 % 8 == 0
+
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True) -> None:
         p1, p2 = self._grads("w")
         gk = p1.grad.permute(0, 2, 3, 1)
-        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(gk), st)
-        config.mark_touched(p1)
-        config.mark_touched(p2)
+        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
+        if final:
+            config.mark_touched(p1)
+            config.mark_touched(p2)
 
 
 class _FusedBN:

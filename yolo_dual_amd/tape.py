@@ -47,7 +47,8 @@ def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
 
 class Var:
     """A NHWC activation: ``t`` is a logical (N,C,H,W) torch view whose memory is [N][H][W][ld] with c fastest."""
-    __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt", "rep", "alias")
+    __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt", "rep", "alias",
+                 "cat_parts", "real")
 
     def __init__(self, tape: "Tape", t: torch.Tensor, ld: int, need: bool, parent: Optional["Var"] = None, c0: int = 0):
         self.tape = tape
@@ -67,6 +68,12 @@ class Var:
         # those ops identical to the un-replicated one.
         self.rep = (1, 1)
         self.alias = False      # full-range view of ``parent`` (lazy / materialise views): shares its gradient state
+        # virtual channel concat (Tape.concat): no memory behind ``t`` (a zero-stride placeholder of the right shape);
+        # cat_parts = [(source Var, first channel, needs bilinear resize)].  A 1x1 convolution consumes the parts
+        # directly (conv over a concat = sum of convs over the sources, and a 1x1 conv commutes with the resize);
+        # every other consumer goes through Tape.materialize, which builds the real tensor once (``real``).
+        self.cat_parts = None
+        self.real = None
 
     def root(self) -> "Var":
         v = self
@@ -90,6 +97,10 @@ class Var:
     def lazy(self) -> bool:
         return self.rep != (1, 1)
 
+    @property
+    def virtual(self) -> bool:
+        return self.cat_parts is not None
+
     def is_set(self) -> bool:
         v = self.root()
         return v.gset or (v.parent is not None and v.parent.is_set())
@@ -99,6 +110,7 @@ class Var:
         return self.parent is None or self.alias and self.parent.aligned() or (self.c0 % 8 == 0 and self.C % 8 == 0 and self.parent.aligned())
 
     def slice(self, c0: int, c1: int) -> "Var":
+        assert self.cat_parts is None, "materialize a virtual concat before slicing it"
         v = Var(self.tape, self.t[:, c0:c1], self.ld, self.need, parent=self, c0=c0)
         self.children.append(v)
         return v
@@ -191,13 +203,20 @@ class Tape:
     # ------------------------------------------------------------------ lazy nearest up-sampling
     def upsample_lazy(self, x: Var, fh: int, fw: int) -> Var:
         """nearest up-sampling by integer factors without touching memory (see Var.rep)"""
+        if x.virtual:
+            x = self.materialize(x)
         v = Var(self, x.t, x.ld, x.need, parent=x, c0=0)
         v.alias = True
         v.rep = (x.rep[0] * fh, x.rep[1] * fw)
         return v
 
     def materialize(self, x: Var, out: Optional[Var] = None) -> Var:
-        """turn a lazy Var into a real (LH, LW) tensor (nearest replication kernel; backward sums the replicas)"""
+        """turn a lazy Var into a real (LH, LW) tensor (nearest replication kernel; backward sums the replicas);
+        a virtual concat becomes the real concatenated tensor"""
+        if x.virtual:
+            if x.real is None:
+                x.real = self._concat_real([v for (v, _c0, _rs) in x.cat_parts], True)
+            x = x.real
         if not x.lazy:
             return x if out is None else self.copy(x, out)
         fh, fw = x.rep
@@ -248,6 +267,19 @@ class Tape:
             raise RuntimeError(f"Conv layer input channel mismatch: got {x.C}, weight expects {Cin}")
         outs = list(out) if isinstance(out, (list, tuple)) else None
         rep = 1
+        virt = None
+        if x.virtual:
+            # conv1x1(cat(a.., bilinear_up(b))) = sum_a conv1x1_a(a) + bilinear_up(conv1x1_b(b)): worth it when the
+            # up-sampled source is much wider than the output (the 512-channel 1/16-scale map of the yolov5 head)
+            rs = [v for (v, _c0, r_) in x.cat_parts if r_]
+            if (k == 1 and s == 1 and p == 0 and res is None and m.splittable() and Cin % 8 == 0
+                    and rs[0].C >= 2 * Cout and (outs is None or all(o.aligned() for o in outs))
+                    and (outs is not None or out is None or out.aligned())):
+                virt = [(self.materialize(v) if (v.lazy or not v.aligned()) else v, c0_, r_) for (v, c0_, r_) in x.cat_parts]
+                virt = [(v if v.aligned() else self.copy(v, self.new(v.N, v.C, v.H, v.W, need=v.need)), c0_, r_)
+                        for (v, c0_, r_) in virt]
+            else:
+                x = self.materialize(x)
         if x.lazy:
             if k == 1 and s == 1 and p == 0 and res is None and out is None:
                 rep = x.rep[0] * x.rep[1]           # point-wise: run at the stored size, stay lazy
@@ -280,22 +312,54 @@ class Tape:
         for o in outs:
             parts.append((c0, o.C, o))
             c0 += o.C
-        geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld)
-        gp = ctypes.byref(geom)
         st = _stream()
         w, wt = m.compute_weights(self)
         npix = x.N * Ho * Wo
         cf = m.coeffs(self.device)                   # dict of f32 [Cp] tensors: mean, invstd, scale, shift
+        es = w.element_size()
+        Cin_p, Cout_p = round_up(Cin, 8), round_up(Cout, 8)
+        if virt is None:
+            geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld, 0)
+            subs = None
+        else:
+            # one sub-convolution per source, on column block [c0, c0+C) of the weight matrix (row stride = Cin_p)
+            subs = []
+            for (v, c0_, r_) in virt:
+                gv = L.ConvGeom(v.N, v.H, v.W, v.C, v.H, v.W, Cout, 1, 1, 0, v.ld, y.ld, Cin_p)
+                subs.append((v, c0_, r_, gv))
+            subs.sort(key=lambda e: not e[2])        # the resized source first: it initialises y
+            geom = subs[-1][3]                       # the launch that writes the BN partials
+        gp = ctypes.byref(geom)
+
+        def conv_fwd(ws_ptr):
+            if subs is None:
+                L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), ws_ptr, 0, st)
+                return
+            first = True
+            for i, (v, c0_, r_, gv) in enumerate(subs):
+                wv = ctypes.c_void_p(w.data_ptr() + c0_ * es)
+                last = i == len(subs) - 1
+                if r_:
+                    z = self.new(v.N, Cout, v.H, v.W)
+                    gz = L.ConvGeom(v.N, v.H, v.W, v.C, v.H, v.W, Cout, 1, 1, 0, v.ld, z.ld, Cin_p)
+                    L.call("ydl_conv_fwd", ctypes.byref(gz), self.dt, _p(v.t), wv, _p(z.t), None, 0, st)
+                    L.call("ydl_resize_fwd", self.dt, L.RESIZE_BILINEAR, _p(z.t), z.ld, _p(y.t), y.ld, v.N, v.H, v.W, Ho, Wo,
+                           Cout, 0.0, 0.0, st)
+                else:
+                    L.call("ydl_conv_fwd", ctypes.byref(gv), self.dt, _p(v.t), wv, _p(y.t), ws_ptr if last else None,
+                           0 if first else 1, st)
+                first = False
+
         if self.train:
             nbytes = L.lib().ydl_conv_fwd_stats_ws_bytes(gp, self.dt)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-            L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), _p(ws), st)
-            L.call("ydl_bn_finalize", _p(ws), L.lib().ydl_conv_fwd_grid_m(gp), L.lib().ydl_conv_fwd_block_m(gp),
+            conv_fwd(_p(ws))
+            L.call("ydl_bn_finalize", _p(ws), L.lib().ydl_conv_fwd_grid_m(gp, self.dt), L.lib().ydl_conv_fwd_block_m(gp, self.dt),
                    npix, Cout, _p(m.bn.weight), _p(m.bn.bias), m.bn.eps, m.bn.momentum,
                    _p(m.bn.running_mean), _p(m.bn.running_var), _p(cf["mean"]), _p(cf["invstd"]),
                    _p(cf["scale"]), _p(cf["shift"]), rep, st)
         else:
-            L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), None, st)
+            conv_fwd(None)
             L.call("ydl_bn_eval_coeffs", Cout, _p(m.bn.weight), _p(m.bn.bias), _p(m.bn.running_mean),
                    _p(m.bn.running_var), m.bn.eps, _p(cf["scale"]), _p(cf["shift"]), st)
         single = len(parts) == 1
@@ -349,6 +413,9 @@ class Tape:
             # weight gradient (f32, KRSC) accumulated into the parameter's grad storage; on the side stream when the
             # input gradient is needed too, so wgrad and dgrad of a layer overlap
             from . import config as _cfg
+            if subs is not None:
+                self._bw_split(m, subs, dy, wt, Cout_p, Ho, Wo, st2)
+                return
             if x.need and _cfg.overlap_wgrad():
                 side = side_stream(self.device)
                 side.wait_stream(torch.cuda.current_stream())
@@ -368,6 +435,40 @@ class Tape:
 
         self.bw.append(bw)
         return ret
+
+    def _bw_split(self, m, subs, dy: Var, wt: torch.Tensor, Cout_p: int, Ho: int, Wo: int, st2) -> None:
+        """backward of the commuted conv-over-concat: per source one wgrad into its column block of the weight gradient
+        and one dgrad with its row block of wt; the resized source sees d z = bilinear_up^T (dy)."""
+        from . import config as _cfg
+        es = wt.element_size()
+        jobs = []
+        for (v, c0_, r_, gv) in subs:
+            d = dy
+            if r_:
+                d = self.new(v.N, dy.C, v.H, v.W)
+                L.call("ydl_resize_bwd", self.dt, L.RESIZE_BILINEAR, _p(dy.t), dy.ld, _p(d.t), d.ld, 0,
+                       v.N, v.H, v.W, Ho, Wo, dy.C, 0.0, 0.0, st2)
+                gv = L.ConvGeom(v.N, v.H, v.W, v.C, v.H, v.W, dy.C, 1, 1, 0, v.ld, d.ld, gv.ldw)
+            jobs.append((v, c0_, gv, d))
+        overlap = _cfg.overlap_wgrad() and any(v.need for (v, _c, _g, _d) in jobs)
+        if overlap:
+            side = side_stream(self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i, (v, c0_, gv, d) in enumerate(jobs):
+                    m.wgrad(self, ctypes.byref(gv), v, d, _stream(), col0=c0_, final=(i == len(jobs) - 1))
+            self._keep.extend(d for (_v, _c, _g, d) in jobs)
+            self._keep.append(dy)
+            self._side_used = True
+        else:
+            for i, (v, c0_, gv, d) in enumerate(jobs):
+                m.wgrad(self, ctypes.byref(gv), v, d, st2, col0=c0_, final=(i == len(jobs) - 1))
+        for (v, c0_, gv, d) in jobs:
+            if v.need:
+                gx, acc = self.grad_target(v)
+                wtv = ctypes.c_void_p(wt.data_ptr() + c0_ * Cout_p * es)
+                L.call("ydl_conv_dgrad", ctypes.byref(gv), self.dt, _p(d.t), wtv, _p(gx), acc, st2)
+        self._keep.append(tuple(g for (_v, _c, g, _d) in jobs))      # ctypes structs outlive the enqueue
 
     # ------------------------------------------------------------------ pooling / resize / copies
     def maxpool(self, x: Var, k: int, s: int, p: int, out: Optional[Var] = None) -> Var:
@@ -418,7 +519,7 @@ class Tape:
 
     def copy(self, x: Var, out: Var) -> Var:
         """out[:] = x (channel-slice aware); backward adds d(out) into d(x)."""
-        if x.lazy:
+        if x.lazy or x.virtual:
             return self.materialize(x, out=out)
         L.call("ydl_copy2d", x.dt, _p(x.t), x.ld, _p(out.t), out.ld, x.npix, x.C, 0, _stream())
         if self.record:
@@ -432,7 +533,27 @@ class Tape:
 
     def concat(self, xs: Sequence[Var], align: bool = True) -> Var:
         """Concat along channels with the reference's auto-align (bilinear, align_corners=False, to the first
-        input's size) — seg_diceloss_yolov5.py:484-507.  Each source is written straight into its slice."""
+        input's size) — seg_diceloss_yolov5.py:484-507.
+        When exactly one source has to be up-sampled and everything is 16-byte aligned the result is VIRTUAL (see
+        Var.cat_parts): the typical consumer is a 1x1 convolution, which then never needs the up-sampled tensor."""
+        from . import config as _cfg
+        H, W = xs[0].LH, xs[0].LW
+        ups = [v for v in xs if (v.LH, v.LW) != (H, W)]
+        if (_cfg.commute_concat() and align and len(ups) == 1 and ups[0].LH < H and ups[0].LW < W
+                and all(v.C % 8 == 0 and not v.virtual for v in xs) and len({v.dt for v in xs}) == 1):
+            Ct = sum(v.C for v in xs)
+            ph = torch.empty(1, dtype=self.tdt if xs[0].dt != L.YDL_F32 else torch.float32, device=self.device)
+            cat = Var(self, ph.expand(xs[0].N, Ct, H, W), round_up(Ct, 8), any(v.need for v in xs))
+            parts, c0 = [], 0
+            for v in xs:
+                parts.append((v, c0, (v.LH, v.LW) != (H, W)))
+                c0 += v.C
+            cat.cat_parts = parts
+            return cat
+        return self._concat_real(xs, align)
+
+    def _concat_real(self, xs: Sequence[Var], align: bool) -> Var:
+        """each source is written (copied / bilinearly resized) straight into its channel slice"""
         H, W = xs[0].LH, xs[0].LW
         Ct = sum(v.C for v in xs)
         cat = self.new(xs[0].N, Ct, H, W, f32=(xs[0].dt == L.YDL_F32))
@@ -451,6 +572,8 @@ class Tape:
     # ------------------------------------------------------------------ softmax head
     def softmax(self, x: Var) -> Var:
         """nn.Softmax(1) into an f32 NHWC Var (probabilities stay f32 even in bf16 mode)."""
+        if x.virtual:
+            x = self.materialize(x)
         out = self.new(x.N, x.C, x.H, x.W, zero=True, f32=True)
         out.rep = x.rep                                   # point-wise: stays lazy
         sn, sc, sh, sw = out.t.stride()
@@ -472,6 +595,7 @@ class Tape:
         The region owner must call softmax_nchw_backward with the incoming gradient.
         When x is a lazily up-sampled tensor the stored-resolution probabilities are kept as well (``self.lazy_out``):
         SegmentationLoss uses them to evaluate the loss and its gradient per stored pixel (ydl_seg_loss_rep_*)."""
+        assert not x.virtual
         p = torch.empty((x.N, x.C, x.LH, x.LW), dtype=torch.float32, device=self.device)
         sn, sc, sh, sw = p.stride()
         L.call("ydl_softmax_fwd", x.dt, _p(x.t), x.ld, _p(p), sn, sc, sh, sw, x.N, x.H, x.W, x.C, x.rep[0], x.rep[1],
