@@ -1039,7 +1039,7 @@ struct Wgrad2Args {
 };
 
 template <int TCO>
-__global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wgrad2Args p) {
     constexpr int WCO = TCO / 64;              // waves along cout
     constexpr int WJ = 4 / WCO;                // waves along j
     constexpr int JW = 128 / WJ;               // j columns per wave
@@ -1079,14 +1079,16 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 vy[YR], vx[4];
-    auto gload = [&](int p0) {
+    // two register sets: the loads of stage s+2 are issued while stage s is multiplied and stage s+1 (already in
+    // registers) is written to the other LDS buffer => every global load has two full stages to land
+    uint4 vy[2][YR], vx[2][4];
+    auto gload = [&](int p0, uint4 (&ry)[YR], uint4 (&rx)[4]) {
 #pragma unroll
         for (int i = 0; i < YR; ++i) {
             int m = p0 + yr + (256 / YCH) * i;
             unsigned off = (yv && m < pend) ? (unsigned)(m * p.ldy + co_chunk) * 2u : 0xFFFFFFFFu;
             u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0);
-            vy[i] = make_uint4(v.x, v.y, v.z, v.w);
+            ry[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1099,26 +1101,19 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
             bool ok = qv && m < pend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
             unsigned off = ok ? (unsigned)(((int)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * 2u : 0xFFFFFFFFu;
             u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
-            vx[i] = make_uint4(v.x, v.y, v.z, v.w);
+            rx[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const uint4 (&ry)[YR], const uint4 (&rx)[4]) {
 #pragma unroll
         for (int i = 0; i < YR; ++i)
-            *(uint4*)(sY + buf * (64 * W2_ROWB) + w2sw(yr + (256 / YCH) * i, yq * 16)) = vy[i];
+            *(uint4*)(sY + buf * (64 * W2_ROWB) + w2sw(yr + (256 / YCH) * i, yq * 16)) = ry[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *(uint4*)(sX + buf * (64 * W2_ROWB) + w2sw(xr + 16 * i, xq * 16)) = vx[i];
+            *(uint4*)(sX + buf * (64 * W2_ROWB) + w2sw(xr + 16 * i, xq * 16)) = rx[i];
     };
-
-    gload(pbeg);
-    sstore(0);
-    __syncthreads();
     const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
-    int cur = 0;
-    for (int p0 = pbeg; p0 < pend; p0 += 64) {
-        const bool more = p0 + 64 < pend;
-        if (more) gload(p0 + 64);
+    auto compute = [&](int cur) {
         const unsigned char* by = sY + cur * (64 * W2_ROWB);
         const unsigned char* bx = sX + cur * (64 * W2_ROWB);
 #pragma unroll
@@ -1145,9 +1140,23 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const Wgrad2Args p) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) Mma<bf16_t>::run(af[a], bfv[b], acc[a][b]);
         }
-        if (more) sstore(cur ^ 1);
+    };
+
+    gload(pbeg, vy[0], vx[0]);
+    gload(pbeg + 64, vy[1], vx[1]);            // rows beyond pend load zeros: an odd stage count just multiplies zeros
+    sstore(0, vy[0], vx[0]);
+    __syncthreads();
+    // stage s is multiplied from LDS buffer (s & 1); at an even stage register set 1 holds stage s+1 and set 0 is free.
+    // Straight-line pairs (no early exit): the accumulators stay in one register set.
+    for (int p0 = pbeg; p0 < pend; p0 += 128) {
+        gload(p0 + 128, vy[0], vx[0]);
+        compute(0);
+        sstore(1, vy[1], vx[1]);
         __syncthreads();
-        cur ^= 1;
+        gload(p0 + 192, vy[1], vx[1]);
+        compute(1);
+        sstore(0, vy[0], vx[0]);
+        __syncthreads();
     }
     const size_t wrow = (size_t)p.ntaps * p.Kc;
 #pragma unroll
@@ -1185,7 +1194,23 @@ static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, 
     int ctiles = (g->Cout + TCO - 1) / TCO;
     long tiles = (long)jtiles * ctiles;
     int stages = (a.M + 63) / 64;
-    int splits = (int)((1024 + tiles - 1) / tiles);
+    // Split-K CTA count.  Every CTA ends with one atomic pass over its 128 x TCO f32 tile, and device-scope f32 atomics
+    // sustain only ~1.3 TB/s chip-wide (measured), so the atomic volume T * tile_bytes is budgeted at ~20-30 % of the
+    // layer's streaming/MFMA time: short 1x1 layers get 256 CTAs, long 3x3 layers up to 2048 (measured optimum per layer
+    // on MI355X: 128->128 k1 @160: 256 CTAs 55 us vs 1024 CTAs 92 us; 128->64 k3 @160: 1024-1536 CTAs).
+    static const long forced = getenv("YDL_WG2_CTAS") ? atol(getenv("YDL_WG2_CTAS")) : 0;
+    long target2 = forced;
+    if (!target2) {
+        const double bytes_in = ((double)g->N * g->Hi * g->Wi * g->Cin + (double)a.M * g->Cout) * 2.0;
+        const double flops = 2.0 * a.M * g->Cout * a.ntaps * a.Kc;
+        const double d0 = bytes_in / 4.5e12 > flops / 450e12 ? bytes_in / 4.5e12 : flops / 450e12;
+        const double share = a.Kc <= 16 ? 0.3 : 0.2;      // measured: the 3-channel stem prefers more, shorter CTAs
+        const double t = share * d0 * 1.3e12 / (128.0 * TCO * 4.0);
+        target2 = (long)(t / 256.0 + 0.5) * 256;
+        if (target2 < 256) target2 = 256;
+        if (target2 > 2048) target2 = 2048;
+    }
+    int splits = (int)((target2 + tiles - 1) / tiles);
     if (splits > stages / 4) splits = stages / 4;
     if (splits < 1) splits = 1;
     if (splits > 1024) splits = 1024;
@@ -1243,7 +1268,9 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     // so splits are bounded by an atomic-byte budget as well as by the CTA target (env knobs for tuning runs)
     long tiles = (long)jtiles * ctiles;
     int stages = (a.M + WG_BKP - 1) / WG_BKP;
-    static const long target_ctas = getenv("YDL_WG_CTAS") ? atol(getenv("YDL_WG_CTAS")) : 2048;
+    // (measured: the short 1x1 layers are atomic-bound earlier: 1024 CTAs beat 2048 there, 3x3 layers are flat 2048-4096)
+    static const long forced_ctas = getenv("YDL_WG_CTAS") ? atol(getenv("YDL_WG_CTAS")) : 0;
+    const long target_ctas = forced_ctas ? forced_ctas : (a.ntaps == 1 ? 1024 : 2048);
     static const long atomic_budget = getenv("YDL_WG_ATOMIC_MB") ? atol(getenv("YDL_WG_ATOMIC_MB")) * (1l << 20) : (1l << 40);
     int splits = (int)((target_ctas + tiles - 1) / tiles);
     long dw_bytes = (long)g->Cout * a.ntaps * a.Kc * 4;
