@@ -268,6 +268,43 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     // ---------------- epilogue: store ----------------
     T* Cg = (T*)p.C;
     const int cq = (lane >> 4) * 4;
+    // accumulate: fold the previous contents of C into the accumulators first (whole-vector updates in a separate pass:
+    // keeps the store loop and the statistics below free of per-element selects, which cost 100+ VGPRs when fused)
+    if (p.accumulate) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            int m = m0 + wp * (BM / 4) + j * 16 + lrow;
+            if (m < p.M) {
+                int gw = m % p.Wg;
+                int tmp = m / p.Wg;
+                int gh = tmp % p.Hg;
+                int n = tmp / p.Hg;
+                size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + p.out_h0)) * p.Wo + (gw * p.out_mul + p.out_w0);
+                const T* src = Cg + pix * p.ldc;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    int co = n0 + wc * BNW + c * 16 + cq;
+                    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (co + 3 < p.Cst) {
+                        if constexpr (sizeof(T) == 4) {
+                            float4 q4 = *(const float4*)(src + co);
+                            o = f32x4{q4.x, q4.y, q4.z, q4.w};
+                        } else {
+                            uint2 q2 = *(const uint2*)(src + co);
+                            o = f32x4{__uint_as_float(q2.x << 16), __uint_as_float(q2.x & 0xffff0000u),
+                                      __uint_as_float(q2.y << 16), __uint_as_float(q2.y & 0xffff0000u)};
+                        }
+                    } else {
+                        float t0 = co < p.Cst ? ET<T>::ld(src + co) : 0.f;
+                        float t1 = co + 1 < p.Cst ? ET<T>::ld(src + co + 1) : 0.f;
+                        float t2 = co + 2 < p.Cst ? ET<T>::ld(src + co + 2) : 0.f;
+                        o = f32x4{t0, t1, t2, 0.f};
+                    }
+                    acc[c][j] += o;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         int m = m0 + wp * (BM / 4) + j * 16 + lrow;
@@ -282,32 +319,18 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
             for (int c = 0; c < CT; ++c) {
                 int co = n0 + wc * BNW + c * 16 + cq;
                 if (co + 3 < p.Cst) {
-                    float v[4] = {acc[c][j][0], acc[c][j][1], acc[c][j][2], acc[c][j][3]};
                     if constexpr (sizeof(T) == 4) {
-                        float4* d4 = (float4*)(dst + co);
-                        if (p.accumulate) { float4 o = *d4; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                        *d4 = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(dst + co) = make_float4(acc[c][j][0], acc[c][j][1], acc[c][j][2], acc[c][j][3]);
                     } else {
-                        uint2* d2 = (uint2*)(dst + co);
-                        if (p.accumulate) {
-                            uint2 o = *d2;
-                            v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-                            v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
-                        }
                         uint2 u;
-                        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                        *d2 = u;
+                        u.x = (uint32_t)f2bf(acc[c][j][0]) | ((uint32_t)f2bf(acc[c][j][1]) << 16);
+                        u.y = (uint32_t)f2bf(acc[c][j][2]) | ((uint32_t)f2bf(acc[c][j][3]) << 16);
+                        *(uint2*)(dst + co) = u;
                     }
-                    if (p.accumulate) acc[c][j] = f32x4{v[0], v[1], v[2], v[3]};     // the statistics below see the sums
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (co + e < p.Cst) {
-                            float v = acc[c][j][e];
-                            if (p.accumulate) { v += ET<T>::ld(dst + co + e); acc[c][j][e] = v; }
-                            ET<T>::st(dst + co + e, v);
-                        }
+                        if (co + e < p.Cst) ET<T>::st(dst + co + e, acc[c][j][e]);
                 }
             }
         }
