@@ -221,9 +221,9 @@ def main():
         if os.path.exists(tpath):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
             try:
                 tj = json.load(open(tpath))
-                ig = [k for k in tj["kernels"] if "igemm_kernel" in k["kernel"]]
+                ig = [k for k in tj["kernels"] if "igemm_kernel" in k["kernel"] or "pw_kernel" in k["kernel"]]
                 n_l = sum(k["launches_per_step"] for k in ig)
-                traffic = {"unit": "MB per launch (igemm fwd+dgrad launches, PMC, FETCH_SIZE x2 per the gfx950 note)",
+                traffic = {"unit": "MB per launch (conv fwd+dgrad launches: igemm_kernel + pw_kernel, PMC, FETCH_SIZE x2 per the gfx950 note)",
                            "value": sum(k["fetch_MB"] + k["write_MB"] for k in ig) / max(n_l, 1)}
             except Exception:
                 traffic = None

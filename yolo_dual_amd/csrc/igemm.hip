@@ -1309,7 +1309,8 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     hipStream_t st = (hipStream_t)stream;
     // measured on MI355X: the 128-wide pipelined kernel wins on the large-M layers (>= 160x160 at bs 16), the small
     // 64x64-tile kernel (8 CTAs/CU) wins where M is small and the grid of big tiles would be latency-bound
-    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && a.M >= 200000 && a.M < (1 << 21)) return launch_wgrad2(g, x, dy, dw, st);
+    static const int wg2_min_m = getenv("YDL_WG2_MINM") ? atoi(getenv("YDL_WG2_MINM")) : 200000;
+    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && a.M >= wg2_min_m && a.M < (1 << 21)) return launch_wgrad2(g, x, dy, dw, st);
     if (dtype == YDL_F32) wgrad_kernel<float, false><<<grid, 256, 0, st>>>(a);
     else if (g_wgrad_tr) wgrad_kernel<bf16_t, true><<<grid, 256, 0, st>>>(a);
     else wgrad_kernel<bf16_t, false><<<grid, 256, 0, st>>>(a);
