@@ -324,6 +324,32 @@ def test_loss_fast_path_survives_only_untouched_predictions():
         assert rel_err(gr, res[0][1]) < 2e-4
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_batched_weight_prep_matches_single(mode):
+    """the tiled (LDS-transposed) multi-layer weight re-layout == the element-wise single-layer kernel, padding included"""
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd.tape import _p, _stream
+    dt, tdt = (L.YDL_F32, torch.float32) if mode == "f32" else (L.YDL_BF16, torch.bfloat16)
+    r8 = lambda v: (v + 7) // 8 * 8
+    shapes = [(64, 36, 3), (12, 1, 64), (40, 9, 24), (128, 1, 640), (72, 9, 100)]       # (Cout, k*k, Cin)
+    torch.manual_seed(0)
+    rows, refs, outs = [], [], []
+    for (co, kk, ci) in shapes:
+        master = torch.randn(co, kk, ci, device="cuda")
+        w1 = torch.full((co, kk, r8(ci)), 7.0, device="cuda", dtype=tdt)
+        t1 = torch.full((ci, kk, r8(co)), 7.0, device="cuda", dtype=tdt)
+        w2, t2 = w1.clone(), t1.clone()
+        L.call("ydl_weight_prep", dt, _p(master), _p(w1), _p(t1), co, kk, ci, _stream())
+        rows.append([master.data_ptr(), w2.data_ptr(), t2.data_ptr(), co, kk, ci, 0, 0])
+        refs.append((w1, t1, master))
+        outs.append((w2, t2))
+    desc = torch.tensor(rows, dtype=torch.int64).cuda()
+    L.call("ydl_weight_prep_batched", dt, _p(desc), len(rows), _stream())
+    torch.cuda.synchronize()
+    for (w1, t1, _m), (w2, t2) in zip(refs, outs):
+        assert torch.equal(w1, w2) and torch.equal(t1, t2)
+
+
 def test_sgd_ema_flat_optimizer():
     """FlatSGDEMA == smart_optimizer(SGD nesterov) + ModelEMA on the reference's own 3-step trajectory."""
     import torch.nn as nn

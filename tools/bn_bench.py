@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 from yolo_dual_amd import _lib as L
 
-SHAPES = [(409600, 128, 3200), (409600, 64, 3200), (102400, 256, 800), (25600, 512, 400), (6400, 1024, 100), (6400, 512, 100),
+SHAPES = [(1638400, 64, 12800), (409600, 128, 3200), (409600, 64, 3200), (102400, 256, 800), (25600, 512, 400), (6400, 1024, 100), (6400, 512, 100),
           (409600, 128, 493)]   # (npix, C, conv partial rows)
 dev = torch.device("cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -3,12 +3,11 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------------
-// finalize: Chan-merge of the per-block (sum, M2) partials written by the conv epilogue.
+// finalize: merge of the per-block (sum, M2) partials written by the conv epilogue.
 // partials: [nblocks][2][ldp]; block b covered n_b = min(block_m, count - b*block_m) pixels.
-// Two levels so that no thread walks a long dependent chain: level 1 (grid.y = chunks of MERGE_CHUNK blocks)
-// merges each chunk to one (sum, M2) partial; level 2 merges the chunk partials and writes the coefficients.
-// A CTA is 32 channels x 8 slices; merges are done in double.
 // ------------------------------------------------------------------------------------------------------
+// level-1 pre-merge for very long partial lists (> 1024 rows: the 160x160 and 320x320 layers of the tiled kernel): chunks of
+// MERGE_CHUNK rows are Chan-merged (two-pass, double) by grid.y CTAs into one (sum, M2) row each
 #define MERGE_CHUNK 64
 
 // merges blocks [b0, b1) for channel c; every thread of the CTA must call it (uses LDS + barriers).
@@ -68,20 +67,57 @@ __global__ __launch_bounds__(256) void bn_merge_level1_kernel(const float* __res
     }
 }
 
+// One-pass merge: with S = sum_b s_b and Q = sum_b (M2_b + s_b^2 / n_b), M2 = Q - S^2 / N (all in double: the
+// subtraction loses log2(mean^2/var) of 53 bits).  8 channels x 32 slices per CTA; a slice walks its rows eight at a
+// time with clamped (always valid) addresses and 0/1 weights, so the loads of a batch are independent and unpredicated.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int block_m,
                                                           long long count, int C, int ldp,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* running_mean, float* running_var,
                                                           float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int rep) {
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    double tot = 0, m2 = 0, n = 0;
-    chan_merge(part, 0, nblocks, block_m, count, c, c < C, ldp, tot, m2, n);
-    if ((threadIdx.x >> 5) == 0 && c < C) {
+    constexpr int CH = 8, NS = 256 / CH, B = 8;      // 8 channels x 32 row slices per CTA, 8 rows per batch
+    __shared__ double sh[2][NS][CH + 1];
+    const int cl = threadIdx.x % CH, sl = threadIdx.x / CH;
+    const int c = blockIdx.x * CH + cl;
+    const int cc = c < C ? c : C - 1;
+    // coefficient loads issued before the merge so that their latency hides behind it
+    const float g = gamma ? gamma[cc] : 1.f, bt = beta ? beta[cc] : 0.f;
+    const float rm = running_mean ? running_mean[cc] : 0.f, rv = running_var ? running_var[cc] : 0.f;
+    const double inv_bm = 1.0 / (double)block_m;
+    const long long last_n = count - (long long)(nblocks - 1) * block_m;
+    const double inv_last = 1.0 / (double)last_n;
+    double S = 0.0, Q = 0.0;
+    for (int base = sl; base < nblocks; base += NS * B) {
+        float sv[B], qv[B];
+        int bi[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int b = base + NS * u;
+            bi[u] = b < nblocks ? b : nblocks - 1;
+            sv[u] = part[(size_t)bi[u] * 2 * ldp + cc];
+            qv[u] = part[(size_t)bi[u] * 2 * ldp + ldp + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const double w = (base + NS * u) < nblocks ? 1.0 : 0.0;
+            const double s = (double)sv[u];
+            const double inb = bi[u] == nblocks - 1 ? inv_last : inv_bm;
+            S += w * s;
+            Q += w * ((double)qv[u] + s * s * inb);
+        }
+    }
+    sh[0][sl][cl] = S;
+    sh[1][sl][cl] = Q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double tot = 0.0, q = 0.0;
+        for (int i = 0; i < NS; ++i) { tot += sh[0][i][cl]; q += sh[1][i][cl]; }
         double mu = tot / (double)count;
+        double m2 = q - tot * mu;
+        if (m2 < 0.0) m2 = 0.0;
         double var = m2 / (double)count;            // biased (normalisation)
         float meanf = (float)mu;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
         mean_o[c] = meanf;
         invstd_o[c] = invstd;
         float sc = g * invstd;
@@ -91,8 +127,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
             // the logical tensor is the stored one replicated `rep` times: M2 and the count scale by rep
             double nl = (double)count * (double)rep;
             double unb = nl > 1.0 ? m2 * (double)rep / (nl - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            running_mean[c] = (1.f - momentum) * rm + momentum * meanf;
+            running_var[c] = (1.f - momentum) * rv + momentum * (float)unb;
         }
     }
 }
@@ -106,7 +142,7 @@ extern "C" int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, 
     hipStream_t st = (hipStream_t)stream;
     const int ldp = round_up(C, 8);
     const float* src = stats_ws;
-    if (nblocks > 2 * MERGE_CHUNK) {
+    if (nblocks > 1024) {
         // level 1 writes behind the level-0 partials (the workspace query reserves the room)
         int nchunks = (nblocks + MERGE_CHUNK - 1) / MERGE_CHUNK;
         float* part2 = const_cast<float*>(stats_ws) + (size_t)nblocks * 2 * ldp;
@@ -115,8 +151,8 @@ extern "C" int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, 
         nblocks = nchunks;
         block_m *= MERGE_CHUNK;
     }
-    bn_finalize_kernel<<<(C + 31) / 32, 256, 0, st>>>(src, nblocks, block_m, (long long)count, C, ldp, gamma, beta, eps,
-                                                      momentum, running_mean, running_var, mean, invstd, scale, shift, replication);
+    bn_finalize_kernel<<<(C + 7) / 8, 256, 0, st>>>(src, nblocks, block_m, (long long)count, C, ldp, gamma, beta, eps,
+                                                    momentum, running_mean, running_var, mean, invstd, scale, shift, replication);
     YDL_LAUNCH_CHECK();
     return 0;
 }
@@ -303,22 +339,28 @@ __global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restri
     __shared__ double sh[2][32][9];
     const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-    if (c < Cp) {
-        int i = sl;
-        for (; i + 32 < nblk; i += 64) {
-            a0 += (double)part[(size_t)i * 2 * Cp + c];
-            b0 += (double)part[(size_t)i * 2 * Cp + Cp + c];
-            a1 += (double)part[(size_t)(i + 32) * 2 * Cp + c];
-            b1 += (double)part[(size_t)(i + 32) * 2 * Cp + Cp + c];
+    const int cc = c < Cp ? c : Cp - 1;
+    const float g0 = (accumulate && dgamma && c < C) ? dgamma[c] : 0.f;     // issued early: hidden behind the merge
+    const float b0 = (accumulate && dbeta && c < C) ? dbeta[c] : 0.f;
+    double a = 0, b = 0;
+    for (int base = sl; base < nblk; base += 32 * 4) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                   // clamped row index: unpredicated, independent loads
+            const int i = base + 32 * u;
+            const int ii = i < nblk ? i : nblk - 1;
+            av[u] = part[(size_t)ii * 2 * Cp + cc];
+            bv[u] = part[(size_t)ii * 2 * Cp + Cp + cc];
         }
-        if (i < nblk) {
-            a0 += (double)part[(size_t)i * 2 * Cp + c];
-            b0 += (double)part[(size_t)i * 2 * Cp + Cp + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double w = (base + 32 * u) < nblk ? 1.0 : 0.0;
+            a += w * (double)av[u];
+            b += w * (double)bv[u];
         }
     }
-    sh[0][sl][cl] = a0 + a1;
-    sh[1][sl][cl] = b0 + b1;
+    sh[0][sl][cl] = a;
+    sh[1][sl][cl] = b;
     __syncthreads();
     if (sl == 0 && c < Cp) {
         double ta = 0.0, tb = 0.0;
@@ -326,8 +368,8 @@ __global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restri
         sums[c] = (float)ta;          // dbeta
         sums[Cp + c] = (float)tb;     // dgamma
         if (c < C) {
-            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)ta : (float)ta;
-            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tb : (float)tb;
+            if (dbeta) dbeta[c] = b0 + (float)ta;
+            if (dgamma) dgamma[c] = g0 + (float)tb;
         }
     }
 }
