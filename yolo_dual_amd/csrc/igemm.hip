@@ -105,17 +105,17 @@ __device__ __forceinline__ void row_reduce(float (&v)[NV], int lrow) {
 // depend on k is hoisted): per row a 32-bit byte offset of its (0,0) tap and a 64-bit tap-validity mask are computed
 // once; a K-step adds one table entry (tap delta) and selects "offset or 0xFFFFFFFF" — the loads are raw buffer
 // loads whose range check returns zeros for the padding taps and the tail rows, so there is no branch.
-template <typename T, int BM, int BN, int NW>
+template <typename T, int BM, int BN, int NW, int WP = 4>
 __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     constexpr int V = ET<T>::V;
     constexpr int ES = sizeof(T);
     constexpr int RPP = NW * 8;                 // tile rows covered by one loader pass (threads / 8 chunks)
     constexpr int AR = BM / RPP;                // A rows per thread
     constexpr int BR = (BN + RPP - 1) / RPP;    // B rows per thread
-    constexpr int WN = NW / 4;                  // wave groups along output channels
+    constexpr int WN = NW / WP;                 // wave groups along output channels (WP groups along pixels)
     constexpr int BNW = BN / WN;                // channels per wave
     constexpr int CT = BNW / 16;                // cout tiles per wave
-    constexpr int PT = BM / 64;                 // pixel tiles per wave
+    constexpr int PT = BM / (16 * WP);          // pixel tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                           // [2][BM][GROWB]
     unsigned char* sB = smem + 2 * BM * GROWB;           // [2][BN][GROWB]
@@ -182,10 +182,23 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     uint4 ra[PF][AR], rb[PF][BR];
     __syncthreads();   // tap tables visible
 
+    // K-steps are loaded strictly in order, so the (tap, chunk-in-tap) position of this thread's chunk is carried from
+    // step to step: +8 chunks with at most one wrap when a tap has >= 8 chunks (the 32-bit division it replaces was a
+    // dozen VALU instructions per K-step); layers with fewer chunks per tap (stem: 1) keep the division.
+    int tap_s = q / cpt, cc_s = q - (q / cpt) * cpt, Q_s = q;
     auto gload = [&](int kk, uint4 (&xa)[AR], uint4 (&xb)[BR]) {
-        const int Q = kk * 8 + q;
-        const int tap = Q / cpt;                      // cpt is a power of two or small: one 32-bit division per K-step
-        const int cc = (Q - tap * cpt) * (V * ES);    // byte offset inside the tap
+        (void)kk;
+        const int Q = Q_s;
+        const int tap = tap_s;
+        const int cc = cc_s * (V * ES);               // byte offset inside the tap
+        Q_s += 8;
+        if (cpt >= 8) {
+            cc_s += 8;
+            if (cc_s >= cpt) { cc_s -= cpt; ++tap_s; }
+        } else {
+            tap_s = Q_s / cpt;
+            cc_s = Q_s - tap_s * cpt;
+        }
         const bool tv = Q < nchunks;
         const int tidx = tv ? tap : 0;
         const unsigned da = (unsigned)(sTapA[tidx] + cc);
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     const int lk0 = (((lane >> 4)) ^ sw_rd) << 4;            // k-step half 0: logical chunk (lane>>4)
     const int lk1 = (((lane >> 4) + 4) ^ sw_rd) << 4;        // k-step half 1: logical chunk 4 + (lane>>4)
     const unsigned char* const fa = sB + (wc * BNW + lrow) * GROWB;
-    const unsigned char* const fb = sA + (wp * (BM / 4) + lrow) * GROWB;
+    const unsigned char* const fb = sA + (wp * (BM / WP) + lrow) * GROWB;
     for (int kk0 = 0; kk0 < nk; kk0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     if (p.accumulate) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            int m = m0 + wp * (BM / 4) + j * 16 + lrow;
+            int m = m0 + wp * (BM / WP) + j * 16 + lrow;
             if (m < p.M) {
                 int gw = m % p.Wg;
                 int tmp = m / p.Wg;
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-        int m = m0 + wp * (BM / 4) + j * 16 + lrow;
+        int m = m0 + wp * (BM / WP) + j * 16 + lrow;
         if (m < p.M) {
             int gw = m % p.Wg;
             int tmp = m / p.Wg;
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     if (p.stats != nullptr) {
         constexpr int NV = 4 * CT;
         float* red = (float*)smem;             // [4][BN]; safe: all LDS reads finished at the last barrier
-        float* smean = red + 4 * BN;           // [BN]
+        float* smean = red + WP * BN;          // [BN]
         const int nvalid = min(BM, p.M - m0);
         const int lgrp = lane >> 4;
         float v[NV];
@@ -367,7 +380,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         __syncthreads();
         float tot = 0.f;
         if (t < BN) {
-            tot = red[t] + red[BN + t] + red[2 * BN + t] + red[3 * BN + t];
+            tot = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < WP; ++g2) tot += red[g2 * BN + t];
             smean[t] = tot / (float)nvalid;
         }
         __syncthreads();
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
                 float t2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < PT; ++j) {
-                    int m = m0 + wp * (BM / 4) + j * 16 + lrow;
+                    int m = m0 + wp * (BM / WP) + j * 16 + lrow;
                     float d = acc[c][j][e] - mu;
                     t2 += (m < p.M) ? d * d : 0.f;
                 }
@@ -395,7 +410,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         }
         __syncthreads();
         if (t < BN && n0 + t < p.Cout) {
-            float m2 = red[t] + red[BN + t] + red[2 * BN + t] + red[3 * BN + t];
+            float m2 = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < WP; ++g2) m2 += red[g2 * BN + t];
             float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
             dst[n0 + t] = tot;
             dst[p.stats_ld + n0 + t] = m2;
@@ -674,17 +691,17 @@ static bool args_pointwise(const IgemmArgs& a) {
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int NW = 4>
+template <typename T, int BM, int BN, int NW = 4, int WP = 4>
 static int launch_igemm(IgemmArgs a, hipStream_t st) {
     a.grid_n = (a.Cst + BN - 1) / BN;
     dim3 grid(((a.M + BM - 1) / BM) * a.grid_n);
     size_t smem = 2 * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, NW, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    igemm_kernel<T, BM, BN, NW><<<grid, NW * 64, smem, st>>>(a);
+    igemm_kernel<T, BM, BN, NW, WP><<<grid, NW * 64, smem, st>>>(a);
     YDL_LAUNCH_CHECK();
     return 0;
 }
@@ -696,6 +713,12 @@ static TileCfg pick_cfg(int M, int Cst) {
     c.BM = 128;
     // small-M layers: shrink the pixel tile so that the grid still covers the 256 CUs a few times
     long blocks = (long)((M + 127) / 128) * ((Cst + c.BN - 1) / c.BN);
+    if (blocks < 512 && c.BN == 128) {
+        // halve the channel tile first (measured 6-11 % faster than halving the pixel tile on the 20x20 layers, equal
+        // elsewhere), then the pixel tile
+        long b1 = (long)((M + 127) / 128) * ((Cst + 63) / 64);
+        if (b1 >= 512) { c.BN = 64; return c; }
+    }
     if (blocks < 512 && c.BN != 16) c.BM = 64;
     if (c.BM == 64 && c.BN == 128) {
         long b2 = (long)((M + 63) / 64) * ((Cst + 127) / 128);
@@ -719,9 +742,16 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = 
     }
     TileCfg c = pick_cfg(a.M, a.Cst);
     if (force_bm) c.BM = force_bm;
+    static const int env_bm = getenv("YDL_FORCE_BM") ? atoi(getenv("YDL_FORCE_BM")) : 0;     // tuning runs only
+    static const int env_bn = getenv("YDL_FORCE_BN") ? atoi(getenv("YDL_FORCE_BN")) : 0;
+    if (env_bm && a.stats == nullptr) c.BM = env_bm;        // (the stats workspace is sized from pick_cfg: keep it for those)
+    if (env_bn && c.BN != 16 && a.Cst >= env_bn) c.BN = env_bn;
     if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
     static const int nw8 = getenv("YDL_NW8") ? atoi(getenv("YDL_NW8")) : 1;
-    if (c.BM == 128 && c.BN == 128) return nw8 ? launch_igemm<T, 128, 128, 8>(a, st) : launch_igemm<T, 128, 128, 4>(a, st);
+    if (c.BM == 128 && c.BN == 128) {
+        if (nw8 == 2) return launch_igemm<T, 128, 128, 4, 2>(a, st);      // 2x2 waves, 64x64 wave tiles (experiment)
+        return nw8 ? launch_igemm<T, 128, 128, 8>(a, st) : launch_igemm<T, 128, 128, 4>(a, st);
+    }
     if (c.BM == 128 && c.BN == 64) return launch_igemm<T, 128, 64>(a, st);
     if (c.BM == 128 && c.BN == 16) return launch_igemm<T, 128, 16>(a, st);
     if (c.BM == 64 && c.BN == 128) return nw8 ? launch_igemm<T, 64, 128, 8>(a, st) : launch_igemm<T, 64, 128, 4>(a, st);
