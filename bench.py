@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="keep wgrad on the main stream")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
     ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -104,8 +106,8 @@ def main():
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(0 if args.one_gpu else local)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -155,21 +157,36 @@ def main():
         #             fastest when the host keeps up (about 7-8 ms of host time per step on an idle CPU)
         #   hipgraph: the whole step captured into two HIP graphs on one stream; ~0.1 ms of host time per step
         # Both are measured for a few steps and the faster one runs the timed region; a refused capture falls back to eager.
+        # With several ranks the choice must be the SAME everywhere (eager ranks all-reduce per bucket from the launch
+        # hooks, graphed ranks all-reduce after the replay): timings are max-reduced and a failed capture on any rank
+        # sends every rank to eager.
+        def agree(vals):
+            if world == 1:
+                return vals
+            tt = torch.tensor(vals, device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return [float(v) for v in tt.tolist()]
+
+        t_eager = quick_ms(step)
+        gstep, t_graph, failed = None, float("inf"), 0.0
         try:
             from yolo_dual_amd.graph import GraphedTrainStep
-            t_eager = quick_ms(step)
             ydl.config.set_overlap_wgrad(False)
             gstep = GraphedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=2)
-            t_graph = quick_ms(gstep.step)
-            if t_graph < t_eager:
-                eager_step, step, mode = step, gstep.step, "hipgraph"
-            else:
-                ydl.config.set_overlap_wgrad(not args.no_overlap)
-            print(f"[bench] eager {t_eager:.2f} ms/step, hipgraph {t_graph:.2f} ms/step -> {mode}", file=sys.stderr)
         except Exception as e:          # pragma: no cover
-            ydl.config.set_overlap_wgrad(not args.no_overlap)
-            print(f"[bench] graph capture unavailable, running eager: {e!r}", file=sys.stderr)
+            failed = 1.0
+            print(f"[bench] graph capture unavailable on rank {rank}: {e!r}", file=sys.stderr)
             torch.cuda.synchronize()
+        failed = agree([failed])[0]
+        if not failed:
+            t_graph = quick_ms(gstep.step)
+        t_eager, t_graph = agree([t_eager, t_graph if t_graph != float("inf") else 1e9])
+        if not failed and t_graph < t_eager:
+            eager_step, step, mode = step, gstep.step, "hipgraph"
+        else:
+            ydl.config.set_overlap_wgrad(not args.no_overlap)
+        if rank == 0:
+            print(f"[bench] eager {t_eager:.2f} ms/step, hipgraph {t_graph:.2f} ms/step -> {mode}", file=sys.stderr)
 
     def fence():
         torch.cuda.synchronize()
@@ -198,8 +215,17 @@ def main():
         # dead head branch overlap with the main chain, which inflates per-kernel durations but shortens the step)
         overlap_was = ydl.config.overlap_wgrad()
         ydl.config.set_overlap_wgrad(False)
-        if mode == "hipgraph":
-            step = eager_step          # per-kernel events need individual launches
+        # rank-local: the other ranks are already past the timed region, so no collective may be issued here
+        if dp:
+            dp.reducer.enabled = False
+
+        def step():          # per-kernel events need individual launches (also when the timed region replayed graphs)
+            opt.zero_grad()
+            out = model(imgs)
+            loss, _items = crit(out, tgts)
+            loss.backward()
+            opt.step(grad_scale=1.0)
+
         step()
         L.profile_begin()
         for _ in range(3):
