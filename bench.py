@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="keep wgrad on the main stream")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
     ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
+    ap.add_argument("--graph-overlap", action="store_true", help="capture the side stream (wgrad / dead branch) into the graphs too")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -171,7 +172,7 @@ def main():
         gstep, t_graph, failed = None, float("inf"), 0.0
         try:
             from yolo_dual_amd.graph import GraphedTrainStep
-            ydl.config.set_overlap_wgrad(False)
+            ydl.config.set_overlap_wgrad(bool(args.graph_overlap) and not args.no_overlap)
             gstep = GraphedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=2)
         except Exception as e:          # pragma: no cover
             failed = 1.0
