@@ -129,6 +129,12 @@ int ydl_copy2d(int dtype, const void* src, int lds, void* dst, int ldd, int64_t 
                void* stream);
 /* layout/dtype conversion at the model edge: NCHW f32 <-> NHWC compute dtype (channels padded with zeros) */
 int ydl_nchw_to_nhwc(int dtype, const float* src, void* dst, int ldd, int N, int C, int H, int W, void* stream);
+/* space-to-depth edge conversion for a stem conv with k % s == 0 and p % s == 0 (seg_diceloss_yolov5.py backbone layer 0:
+ * Conv(3, 64, 6, 2, 2)):  conv(k,s,p) on (H,W,C) == conv(k/s,1,p/s) on (H/s, W/s, s*s*C), channel (dy*s+dx)*C + c.
+ * ydl_weight_prep_s2d / ydl_wgrad_unpack_s2d apply the same index map to the KRSC weight and its gradient. */
+int ydl_nchw_to_s2d(int dtype, const float* src, void* dst, int ldd, int N, int C, int H, int W, int s, void* stream);
+int ydl_weight_prep_s2d(int dtype, const float* master, void* w2, int Cout, int k, int s, int C, void* stream);
+int ydl_wgrad_unpack_s2d(const float* dw2, float* grad, int Cout, int k, int s, int C, int accumulate, void* stream);
 int ydl_nhwc_to_nchw(int dtype, const void* src, int lds, float* dst, int N, int C, int H, int W, int accumulate,
                      void* stream);
 /* generic elementwise on NHWC slices: out = a * b_bcast ... used by GAM (x * gate[n,c]) */

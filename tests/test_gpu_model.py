@@ -244,6 +244,35 @@ def test_commuted_concat_conv_matches_materialised_concat(mode):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("mode,c1,k,st,p", [("f32", 3, 6, 2, 2), ("bf16", 3, 6, 2, 2), ("f32", 1, 4, 2, 0), ("f32", 4, 4, 2, 2),
+                                            ("f32", 3, 6, 3, 3)])
+def test_stem_space_to_depth_matches_plain_conv(mode, c1, k, st, p):
+    """a stem conv with k and p multiples of its stride, on the raw region input, runs as the stride-1 conv over the
+    space-to-depth form (ydl_nchw_to_s2d / ydl_weight_prep_s2d / ydl_wgrad_unpack_s2d): same output, statistics and weight
+    gradient as the plain strided conv (which the golden tests pin to the reference)"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
+    ydl.set_compute_dtype(mode)
+    res = []
+    for on in (True, False):
+        config.set_stem_s2d(on)
+        try:
+            torch.manual_seed(7)
+            m = ydl.Conv(c1, 24, k, st, p).cuda().train()
+            with torch.no_grad():
+                m.conv.weight.normal_(0, 0.2)
+            x = torch.randn(2, c1, 36, 48, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
+            out = m(x)
+            (out * torch.randn(out.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(9))).sum().backward()
+            res.append([t.detach().float().cpu() for t in (out, m.conv.weight.grad, m.bn.running_mean, m.bn.running_var,
+                                                            m.bn.weight.grad, m.bn.bias.grad)])
+        finally:
+            config.set_stem_s2d(True)
+    tol = 2e-5 if mode == "f32" else 3e-2
+    for a, b, nm in zip(res[0], res[1], ("out", "dw", "running_mean", "running_var", "dgamma", "dbeta")):
+        assert a.shape == b.shape and l2_err(a, b) < tol, (nm, l2_err(a, b))
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (bs=16 would need ~10 GB of activations; bs=4 keeps the test quick): size-independent
     checks — probabilities sum to 1, finite loss, every live parameter gets a finite non-zero gradient, and the

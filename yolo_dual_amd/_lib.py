@@ -51,6 +51,9 @@ SIGNATURES = {
     "ydl_resize_bwd": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "ydl_copy2d": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
     "ydl_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ydl_nchw_to_s2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ydl_weight_prep_s2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ydl_wgrad_unpack_s2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ydl_nhwc_to_nchw": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ydl_scale_channels": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i64, _i, _vp]),
     "ydl_global_pool_fwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),

@@ -5,7 +5,8 @@ import os
 
 _STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True, "fuse_siblings": True, "overlap_wgrad": os.environ.get("YDL_OVERLAP_WGRAD", "1") != "0",
           "commute_concat": os.environ.get("YDL_COMMUTE_CONCAT", "1") != "0",
-          "replicated_loss": os.environ.get("YDL_REPLICATED_LOSS", "1") != "0"}
+          "replicated_loss": os.environ.get("YDL_REPLICATED_LOSS", "1") != "0",
+          "stem_s2d": os.environ.get("YDL_STEM_S2D", "1") != "0"}
 
 
 def set_compute_dtype(name: str) -> None:
@@ -55,6 +56,16 @@ def commute_concat() -> bool:
 
 def set_commute_concat(on: bool) -> None:
     _STATE["commute_concat"] = bool(on)
+
+
+def stem_s2d() -> bool:
+    """a stem conv on the raw region input whose k and p are multiples of its stride runs as the equivalent stride-1 conv
+    over the space-to-depth converted input"""
+    return _STATE["stem_s2d"]
+
+
+def set_stem_s2d(on: bool) -> None:
+    _STATE["stem_s2d"] = bool(on)
 
 
 def replicated_loss() -> bool:

@@ -434,6 +434,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
 //     cancellation at that size), converted to (mean, M2) and Chan-merged over the 16 pixel lanes with the transposing
 //     butterfly, then over the CTA's pixel waves through LDS => the same [grid_m][2][C] (sum, M2) contract.
 // ------------------------------------------------------------------------------------------------------
+#ifndef PW_LOAD_AUX
+#define PW_LOAD_AUX 0      // cache-policy bits of the activation loads (bit 1 = nt); measured: see DESIGN.md
+#endif
 struct PwArgs {
     const void* X; const void* W; void* Y; float* stats;
     int M, lda, ldc, Cout, WN, accumulate, block_m, stats_ld;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
         const unsigned base = (unsigned)m * rowbytes + (unsigned)(lgrp << 4);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? base + j * 64 : 0xFFFFFFFFu, 0, 0);
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? base + j * 64 : 0xFFFFFFFFu, 0, PW_LOAD_AUX);
             b[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
@@ -644,7 +647,8 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
     const long wbytes = (long)Cout * RB;
     if (wbytes > 128 * 1024) return pl;
     pl.RB = RB;
-    pl.CT = Cout >= 128 ? 8 : 4;
+    static const int ct4 = getenv("YDL_PW_CT4") ? atoi(getenv("YDL_PW_CT4")) : 0;      // tuning: 64 channels per wave
+    pl.CT = (Cout >= 128 && !(ct4 && Cout == 128)) ? 8 : 4;
     pl.WN = Cout / (pl.CT * 16);
     // 512-byte rows x 128+ channels need ~230 VGPRs: as 4-wave CTAs that is one wave per SIMD; one 8-wave CTA per CU
     // gives two

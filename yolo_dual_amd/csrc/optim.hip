@@ -111,6 +111,65 @@ extern "C" int ydl_wgrad_unpad(const float* dw, float* grad, int Cout, int kk, i
     return 0;
 }
 
+// space-to-depth form of a stem weight (see ydl_nchw_to_s2d): master [Cout][k][k][C] (KRSC) ->
+//   w2[co][(r2*k2 + c2)][(dy*s+dx)*C + c] = master[co][s*r2+dy][s*c2+dx][c],   k2 = k/s, row padded to Cs_p = round_up(s*s*C, 8)
+template <typename T>
+__global__ void weight_prep_s2d_kernel(const float* __restrict__ master, T* __restrict__ w2, int Cout, int k, int s, int C) {
+    const int k2 = k / s, Cs = C * s * s, Cs_p = (Cs + 7) / 8 * 8;
+    const long long total = (long long)Cout * k2 * k2 * Cs_p;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % Cs_p);
+        long long r = i / Cs_p;
+        const int c2 = (int)(r % k2); r /= k2;
+        const int r2 = (int)(r % k2);
+        const int co = (int)(r / k2);
+        float v = 0.f;
+        if (ch < Cs) {
+            const int c = ch % C, dd = ch / C, dx = dd % s, dy = dd / s;
+            v = master[(((size_t)co * k + (s * r2 + dy)) * k + (s * c2 + dx)) * C + c];
+        }
+        ET<T>::st(w2 + i, v);
+    }
+}
+extern "C" int ydl_weight_prep_s2d(int dtype, const float* master, void* w2, int Cout, int k, int s, int C, void* stream) {
+    YDL_CHECK(master && w2 && Cout > 0 && C > 0 && s >= 1 && k % s == 0, "k must be a multiple of s");
+    const int k2 = k / s;
+    long long total = (long long)Cout * k2 * k2 * round_up(C * s * s, 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) weight_prep_s2d_kernel<float><<<grid, 256, 0, st>>>(master, (float*)w2, Cout, k, s, C);
+    else weight_prep_s2d_kernel<bf16_t><<<grid, 256, 0, st>>>(master, (bf16_t*)w2, Cout, k, s, C);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// the inverse index map for the weight gradient: grad[co][s*r2+dy][s*c2+dx][c] (+)= dw2[co][r2*k2+c2][(dy*s+dx)*C + c]
+__global__ void wgrad_unpack_s2d_kernel(const float* __restrict__ dw2, float* __restrict__ grad, int Cout, int k, int s, int C,
+                                        int accumulate) {
+    const int k2 = k / s, Cs = C * s * s, Cs_p = (Cs + 7) / 8 * 8;
+    const long long total = (long long)Cout * k * k * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int kw = (int)(r % k); r /= k;
+        const int kh = (int)(r % k);
+        const int co = (int)(r / k);
+        const int r2 = kh / s, dy = kh % s, c2 = kw / s, dx = kw % s;
+        const float v = dw2[(((size_t)co * k2 + r2) * k2 + c2) * Cs_p + (dy * s + dx) * C + c];
+        grad[i] = accumulate ? grad[i] + v : v;
+    }
+}
+extern "C" int ydl_wgrad_unpack_s2d(const float* dw2, float* grad, int Cout, int k, int s, int C, int accumulate, void* stream) {
+    YDL_CHECK(dw2 && grad && Cout > 0 && C > 0 && s >= 1 && k % s == 0, "k must be a multiple of s");
+    long long total = (long long)Cout * k * k * C;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    wgrad_unpack_s2d_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dw2, grad, Cout, k, s, C, accumulate);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
 // One pass over [params | buffers]: SGD-nesterov on params (two lr/decay groups), EMA on everything.
 //   g = grad*grad_scale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*(g + mom*buf) ; ema = d*ema + (1-d)*p
 __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ params, const float* __restrict__ grads,

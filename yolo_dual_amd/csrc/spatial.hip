@@ -380,6 +380,44 @@ extern "C" int ydl_nchw_to_nhwc(int dtype, const float* src, void* dst, int ldd,
     YDL_LAUNCH_CHECK();
     return 0;
 }
+// Space-to-depth edge conversion for a stem convolution whose kernel size and padding are multiples of its stride s:
+//   conv(k, s, p) on (H, W, C)  ==  conv(k/s, 1, p/s) on (H/s, W/s, s*s*C)   with channel (dy*s+dx)*C + c = pixel (s*h+dy, s*w+dx)
+// (the 6x6/stride-2 stem of the yolov5 backbone becomes a 3x3/stride-1 conv over 12 channels: K = 9*16 instead of the
+// 36*8 of the channel-padded form, and its loader reads 32-byte chunks).  dst is NHWC with pixel stride ldd.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_s2d_kernel(const float* __restrict__ src, T* __restrict__ dst, int ldd,
+                                                          int C, int H, int W, int s) {
+    const int n = blockIdx.y;
+    const int Ho = H / s, Wo = W / s;
+    const long long HWo = (long long)Ho * Wo;
+    const int Cs = C * s * s;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HWo; i += (long long)gridDim.x * blockDim.x) {
+        const int wo = (int)(i % Wo), ho = (int)(i / Wo);
+        T* d = dst + ((size_t)n * HWo + i) * ldd;
+        constexpr int V = ET<T>::V;
+        for (int c0 = 0; c0 < ldd; c0 += V) {            // one 16-byte store per chunk of V channels
+            float f[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ch = c0 + e;
+                const int c = ch % C, dd = ch / C, dx = dd % s, dy = dd / s;
+                f[e] = ch < Cs ? src[(((size_t)n * C + c) * H + (ho * s + dy)) * W + (wo * s + dx)] : 0.f;
+            }
+            *(uint4*)(d + c0) = pack16<T>(f);
+        }
+    }
+}
+extern "C" int ydl_nchw_to_s2d(int dtype, const float* src, void* dst, int ldd, int N, int C, int H, int W, int s, void* stream) {
+    YDL_CHECK(src && dst && s >= 1 && H % s == 0 && W % s == 0 && ldd >= C * s * s && ldd % 8 == 0,
+              "H and W must be multiples of s; ldd must cover C*s*s and be a multiple of 8");
+    long long HWo = (long long)(H / s) * (W / s);
+    dim3 grid((unsigned)((HWo + 255) / 256), N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YDL_F32) nchw_to_s2d_kernel<float><<<grid, 256, 0, st>>>(src, (float*)dst, ldd, C, H, W, s);
+    else nchw_to_s2d_kernel<bf16_t><<<grid, 256, 0, st>>>(src, (bf16_t*)dst, ldd, C, H, W, s);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int ydl_nhwc_to_nchw(int dtype, const void* src, int lds_, float* dst, int N, int C, int H, int W, int accumulate, void* stream) {
     YDL_CHECK(src && dst && lds_ >= round_up(C, dtype == YDL_F32 ? 4 : 8), "source stride must cover C rounded to a chunk");
     long long HW = (long long)H * W;

@@ -54,7 +54,7 @@ class _Region(torch.autograd.Function):
         record = any(ctx.needs_input_grad[2:])
         tape = Tape(config.compute_dtype(), dev, fn.training, record)
         refresh_weights(fn, tape)
-        vs = [tape.input_nchw(t) for t in ins]
+        vs = [tape.input_nchw(t, lazy=not ctx.needs_input_grad[2 + i]) for i, t in enumerate(ins)]
         for i, v in enumerate(vs):
             v.need = bool(ctx.needs_input_grad[2 + i])
         res = fn._fwd(tape, vs if fn.takes_list else vs[0]) if n_in else None
@@ -289,11 +289,68 @@ class Conv(YdlModule):
     def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None, res: Optional[Var] = None,
              res_mode: int = L.RES_NONE, act_code: Optional[int] = None) -> Var:
         self.mark_step(tape)
-        return tape.conv_bn_act(x, self, self.s, self.p, self.act_code if act_code is None else act_code,
-                                out=out, res=res, res_mode=res_mode)
+        act = self.act_code if act_code is None else act_code
+        if (x.ext_src is not None and x.real is None and not x.need and config.stem_s2d() and res is None and self.s > 1
+                and self.k % self.s == 0 and self.p % self.s == 0 and self.c1 * self.s * self.s <= 16
+                and x.H % self.s == 0 and x.W % self.s == 0):
+            # stem on the raw input: conv(k, s, p) == conv(k/s, 1, p/s) over the space-to-depth form (K = 9*16, not 36*8)
+            ad = _S2DStem(self)
+            return tape.conv_bn_act(tape.input_s2d(x.ext_src, self.s), ad, 1, ad.p, act, out=out)
+        return tape.conv_bn_act(x, self, self.s, self.p, act, out=out, res=res, res_mode=res_mode)
 
     def forward_fuse(self, x):
         raise NotImplementedError("inference-time Conv+BN folding is out of scope (SURVEY §8f-2)")
+
+
+class _S2DStem:
+    """View of a stem ``Conv`` (k and p multiples of the stride s) as the stride-1 conv it equals over the space-to-depth
+    input (ydl_nchw_to_s2d): k/s taps per side, s*s*c1 input channels.  Duck-types the part of ``Conv`` the tape uses;
+    weights and gradients go through ydl_weight_prep_s2d / ydl_wgrad_unpack_s2d (same index map as the activation)."""
+
+    def __init__(self, conv: "Conv"):
+        self.m = conv
+        self.k, self.s, self.p = conv.k // conv.s, 1, conv.p // conv.s
+        self.c1, self.c2 = conv.c1 * conv.s * conv.s, conv.c2
+        self.bn, self.act_code = conv.bn, conv.act_code
+
+    def splittable(self) -> bool:
+        return False
+
+    def compute_weights(self, tape: Tape):
+        m = self.m
+        key = m._wkey(tape)
+        c = m._wcache
+        if c.get("s2d_key") != key or c.get("s2d_w") is None:
+            if c.get("s2d_w") is None or c["s2d_w"].dtype != tape.tdt:
+                c["s2d_w"] = torch.empty((self.c2, self.k * self.k, round_up(self.c1, 8)), dtype=tape.tdt,
+                                         device=m.conv.weight.device)
+            L.call("ydl_weight_prep_s2d", tape.dt, _p(m._master_krsc()), _p(c["s2d_w"]), m.c2, m.k, m.s, m.c1, _stream())
+            c["s2d_key"] = key
+        return c["s2d_w"], c["s2d_w"]          # no dgrad: the input is external and needs no gradient
+
+    def coeffs(self, device):
+        return self.m.coeffs(device)
+
+    def grad_slot(self, tape: Tape, which: str):
+        return self.m.grad_slot(tape, which)
+
+    def touch_bn(self) -> None:
+        self.m.touch_bn()
+
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True) -> None:
+        m = self.m
+        p = m.conv.weight
+        g = m._grad_of(p)
+        gk = g.permute(0, 2, 3, 1)
+        tmp = torch.zeros((self.c2, self.k * self.k, round_up(self.c1, 8)), dtype=torch.float32, device=g.device)
+        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(tmp), st)
+        if gk.is_contiguous():
+            L.call("ydl_wgrad_unpack_s2d", _p(tmp), _p(gk), m.c2, m.k, m.s, m.c1, 1, st)
+        else:                                           # exotic grad layout: let torch place it (cold path)
+            k2, s_ = self.k, m.s
+            t6 = tmp[:, :, :self.c1].view(m.c2, k2, k2, s_, s_, m.c1).permute(0, 1, 3, 2, 4, 5).reshape(m.c2, m.k, m.k, m.c1)
+            g.add_(t6.permute(0, 3, 1, 2))
+        config.mark_touched(p)
 
 
 class _FusedPair:

@@ -48,7 +48,7 @@ def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
 class Var:
     """A NHWC activation: ``t`` is a logical (N,C,H,W) torch view whose memory is [N][H][W][ld] with c fastest."""
     __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt", "rep", "alias",
-                 "cat_parts", "real")
+                 "cat_parts", "real", "ext_src")
 
     def __init__(self, tape: "Tape", t: torch.Tensor, ld: int, need: bool, parent: Optional["Var"] = None, c0: int = 0):
         self.tape = tape
@@ -74,6 +74,9 @@ class Var:
         # every other consumer goes through Tape.materialize, which builds the real tensor once (``real``).
         self.cat_parts = None
         self.real = None
+        # lazily converted region input: the caller's (N,C,H,W) f32 tensor; the NHWC copy is made by Tape.materialize on
+        # first use — or never, when the first layer is a stem conv that reads a space-to-depth conversion instead
+        self.ext_src = None
 
     def root(self) -> "Var":
         v = self
@@ -99,7 +102,7 @@ class Var:
 
     @property
     def virtual(self) -> bool:
-        return self.cat_parts is not None
+        return self.cat_parts is not None or self.ext_src is not None
 
     def is_set(self) -> bool:
         v = self.root()
@@ -110,7 +113,7 @@ class Var:
         return self.parent is None or self.alias and self.parent.aligned() or (self.c0 % 8 == 0 and self.C % 8 == 0 and self.parent.aligned())
 
     def slice(self, c0: int, c1: int) -> "Var":
-        assert self.cat_parts is None, "materialize a virtual concat before slicing it"
+        assert not self.virtual, "materialize a virtual Var before slicing it"
         v = Var(self.tape, self.t[:, c0:c1], self.ld, self.need, parent=self, c0=c0)
         self.children.append(v)
         return v
@@ -190,14 +193,27 @@ class Tape:
         return g, acc
 
     # ------------------------------------------------------------------ region boundary
-    def input_nchw(self, x: torch.Tensor) -> Var:
-        """external (N,C,H,W) f32 tensor (any strides) -> internal NHWC compute dtype, channels zero padded"""
+    def input_nchw(self, x: torch.Tensor, lazy: bool = False) -> Var:
+        """external (N,C,H,W) f32 tensor (any strides) -> internal NHWC compute dtype, channels zero padded.
+        ``lazy``: return a virtual Var and convert on first use (see Var.ext_src)"""
         x = x.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.contiguous().float()
         N, C, H, W = x.shape
+        if lazy:
+            ph = torch.empty(1, dtype=self.tdt, device=self.device)
+            v = Var(self, ph.expand(N, C, H, W), round_up(C, 8), False)
+            v.ext_src = x
+            return v
         v = self.new(N, C, H, W, need=False, zero=True)
         L.call("ydl_nchw_to_nhwc", self.dt, _p(x), _p(v.t), v.ld, N, C, H, W, _stream())
+        return v
+
+    def input_s2d(self, src: torch.Tensor, s: int) -> Var:
+        """space-to-depth conversion of an external (N,C,H,W) tensor: (N, s*s*C, H/s, W/s) NHWC Var (ydl_nchw_to_s2d)"""
+        N, C, H, W = src.shape
+        v = self.new(N, C * s * s, H // s, W // s, need=False)
+        L.call("ydl_nchw_to_s2d", self.dt, _p(src), _p(v.t), v.ld, N, C, H, W, s, _stream())
         return v
 
     # ------------------------------------------------------------------ lazy nearest up-sampling
@@ -215,7 +231,10 @@ class Tape:
         a virtual concat becomes the real concatenated tensor"""
         if x.virtual:
             if x.real is None:
-                x.real = self._concat_real([v for (v, _c0, _rs) in x.cat_parts], True)
+                if x.ext_src is not None:
+                    x.real = self.input_nchw(x.ext_src)
+                else:
+                    x.real = self._concat_real([v for (v, _c0, _rs) in x.cat_parts], True)
             x = x.real
         if not x.lazy:
             return x if out is None else self.copy(x, out)
@@ -268,6 +287,8 @@ class Tape:
         outs = list(out) if isinstance(out, (list, tuple)) else None
         rep = 1
         virt = None
+        if x.virtual and x.cat_parts is None:
+            x = self.materialize(x)
         if x.virtual:
             # conv1x1(cat(a.., bilinear_up(b))) = sum_a conv1x1_a(a) + bilinear_up(conv1x1_b(b)): worth it when the
             # up-sampled source is much wider than the output (the 512-channel 1/16-scale map of the yolov5 head)
@@ -285,7 +306,7 @@ class Tape:
                 rep = x.rep[0] * x.rep[1]           # point-wise: run at the stored size, stay lazy
             else:
                 x = self.materialize(x)
-        if res is not None and res.lazy:
+        if res is not None and (res.lazy or res.virtual):
             res = self.materialize(res)
         if not x.aligned():                       # odd channel split: stage through an aligned buffer (cold path)
             x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need))
@@ -537,6 +558,7 @@ class Tape:
         When exactly one source has to be up-sampled and everything is 16-byte aligned the result is VIRTUAL (see
         Var.cat_parts): the typical consumer is a 1x1 convolution, which then never needs the up-sampled tensor."""
         from . import config as _cfg
+        xs = [self.materialize(v) if (v.virtual and v.ext_src is not None) else v for v in xs]
         H, W = xs[0].LH, xs[0].LW
         ups = [v for v in xs if (v.LH, v.LW) != (H, W)]
         if (_cfg.commute_concat() and align and len(ups) == 1 and ups[0].LH < H and ups[0].LW < W
