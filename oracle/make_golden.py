@@ -291,6 +291,28 @@ def gen_models(ns5, ns18):
     _model_fixture("model_resnet18seg_64", m18, ns18["SegmentationLoss"](12, 0.0), x, tgt)
 
 
+def gen_models_more():
+    """ResNet50 + SegmentHead (BASELINE config 3, segment/train.py) and YOLOv9Seg (config 5; yaml `GAM [512]` cannot be
+    built by the reference itself — GAM(c1, 512) — so the fixture uses `GAM []`, like the module's own signature)"""
+    cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+    S = 64
+    x = rs_tensor(200, (2, 3, S, S)).abs().clamp(0, 1)
+    tgt = torch.from_numpy(np.random.RandomState(201).randint(0, 12, size=(2, S, S)).astype(np.int64))
+    nst = load_ref("segment/train.py", [(50, 338)])
+    torch.manual_seed(0)
+    m50 = nst["ResNet50Seg"]({"nc": 12}) if "cfg" in nst["ResNet50Seg"].__init__.__code__.co_varnames else nst["ResNet50Seg"](12)
+    _model_fixture("model_resnet50seg_64", m50, nst["SegmentationLoss"](12, 0.0), x, tgt)
+    ns9 = load_ref("unet-lite/yolo9-seg/seg_diceloss_yolov9.py", [(84, 90), (413, 880)])
+    cfg9 = yaml.safe_load(open(os.path.join(REF, "unet-lite/yolo9-seg/yolov9_seg.yaml")))
+    for sec in ("backbone", "head"):
+        for l in cfg9[sec]:
+            if l[2] == "GAM":
+                l[3] = []
+    m9 = ns9["YOLOv9Seg"](cfg9)
+    m9.img_size = [S, S]
+    _model_fixture("model_yolov9seg_64", m9, ns9["SegmentationLoss"](12, 0.0, cw), x, tgt)
+
+
 def gen_dcnv3():
     ns = load_ref("models/ops_dcnv3/build/lib.linux-x86_64-cpython-38/functions/dcnv3_func.py", [(92, 189)],
                   extra=dict(DCNv3=None))
@@ -356,6 +378,9 @@ def gen_optim():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if "--models-more" in sys.argv:
+        gen_models_more()
+        sys.exit(0)
     ns5 = gen_blocks_v5()
     gen_losses(ns5)
     gen_blocks_common()

@@ -202,14 +202,16 @@ def segment_head(sd: SD, pre: str, feats: Sequence[torch.Tensor], train: bool = 
     return conv_bn_act(sd, pre + ".final_conv.1", y, act="none", train=train)
 
 
-def resnet_seg_forward(sd: SD, x: torch.Tensor, kind: str, train: bool = True) -> torch.Tensor:
-    """ResNet18Seg/ResNet50Seg._forward_once — Resnet18:389-403: backbone, head, bilinear(align_corners=False)
-    to the input size."""
+def resnet_seg_forward(sd: SD, x: torch.Tensor, kind: str, train: bool = True, out_size=None) -> torch.Tensor:
+    """ResNet18Seg._forward_once — Resnet18:389-403: backbone, head, bilinear(align_corners=False) to the input size.
+    ``out_size``: segment/train.py's SegmentHead.forward (:208-209) instead ends with a hard-coded
+    ``F.interpolate(size=(640, 640))`` whatever the input size (ResNet50Seg, BASELINE config 3): pass (640, 640)."""
     blocks = (2, 2, 2, 2) if kind == "basic" else (3, 4, 6, 3)
     feats = resnet_backbone(sd, "backbone", x, blocks, kind, train=train)
     out = segment_head(sd, "head", feats, train=train)
-    if out.shape[2:] != x.shape[2:]:
-        out = F.interpolate(out, size=x.shape[2:], mode="bilinear", align_corners=False)
+    size = tuple(out_size) if out_size is not None else tuple(x.shape[2:])
+    if tuple(out.shape[2:]) != size or out_size is not None:
+        out = F.interpolate(out, size=size, mode="bilinear", align_corners=False)
     return out
 
 

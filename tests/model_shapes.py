@@ -43,6 +43,13 @@ def script_model_state_shapes(cfg):
             _conv(sh, pre + ".cv1", c1, c1 // 2, 1)
             _conv(sh, pre + ".cv2", (c1 // 2) * 4, c2, 1)
             return c2
+        if kind == "GAM":                       # seg_diceloss_yolov9.py:475-490: GAM(c, k=1, s=1, e=0.25)
+            k = args[0] if args else 1
+            c_ = int(c1 * 0.25)
+            _conv(sh, pre + ".conv1", c1, c_, k)
+            _conv(sh, pre + ".conv2", c_, c1, k)
+            _conv(sh, pre + ".conv3", c_, c1, k)
+            return c1
         if kind in ("nn.Upsample", "Upsample", "Concat", "nn.Softmax"):
             return c1
         raise NotImplementedError(kind)

@@ -23,12 +23,13 @@ def _cfg(name, swap):
     return cfg
 
 
-def _train_check(g, model, crit, mode, steps=2, lr=0.01):
+def _train_check(g, model, crit, mode, steps=2, lr=0.01, f32_grad_tol=2e-3, later_loss_tol=None):
     import yolo_dual_amd as ydl
     ydl.set_compute_dtype(mode)
     # bf16 at this toy size (64x64, batch 2: the deepest BatchNorms see 8 values per channel) only checks the loss and
     # the dead-parameter set; bf16 accuracy at a realistic size is test_bf16_tracks_f32 below
-    tol = dict(f32=dict(out=1e-4, loss=1e-4, gn=2e-3, fin=2e-3), bf16=dict(out=None, loss=5e-2, gn=None, fin=None))[mode]
+    tol = dict(f32=dict(out=1e-4, loss=1e-4, gn=f32_grad_tol, fin=f32_grad_tol),
+               bf16=dict(out=None, loss=5e-2, gn=None, fin=None))[mode]
     sd = model.state_dict()
     fill_state_dict(sd, 1234, bn_stats=False)
     model.load_state_dict(sd)
@@ -56,8 +57,9 @@ def _train_check(g, model, crit, mode, steps=2, lr=0.01):
                     bad.append((k, got, n))
             assert not bad, bad[:5]
         ref = g.flat[f"loss_items_{st}"]
+        ltol = tol["loss"] if (st == 0 or later_loss_tol is None or mode != "f32") else later_loss_tol
         for a, b in zip(items, ref):
-            assert abs(a - b) <= tol["loss"] * abs(b), (st, items, ref)
+            assert abs(a - b) <= ltol * abs(b), (st, items, ref)
         opt.step()
     sd = model.state_dict()
     bad = []
@@ -93,6 +95,30 @@ def test_resnet18seg_trajectory(mode):
     g = Golden("model_resnet18seg_64")
     m = ydl.ResNet18Seg({"nc": 12})
     _train_check(g, m, ydl.SegmentationLoss(12, 0.0, None, "dice"), mode)
+
+
+@pytest.mark.parametrize("mode", ["f32"])
+def test_resnet50seg_trajectory(mode):
+    """BASELINE config 3: ResNet50 (SiLU Conv blocks, ReLU residual joins) + multi-scale SegmentHead"""
+    import yolo_dual_amd as ydl
+    g = Golden("model_resnet50seg_64")
+    m = ydl.ResNet50Seg({"nc": 12})
+    # logits and loss are held to 1e-4; the gradient NORMS of this 53-conv net on a 64x64 input (BatchNorm over 32 values in
+    # layer3) are only reproducible to ~1 % in fp32: the CPU oracle in f32 vs f64 differs by 1.6 % (median, element-wise),
+    # this path in f32 vs the f64 oracle by 1.1 % (tools/r50_debug.py) — hence 1e-2 here instead of 2e-3
+    # (the loss after the first update inherits that gradient noise: 2.3e-4 measured, bound 1e-3; step 0 — identical
+    # weights and inputs — stays at 1e-4)
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, None, "dice"), mode, f32_grad_tol=1e-2, later_loss_tol=1e-3)
+
+
+@pytest.mark.parametrize("mode", ["f32"])
+def test_yolov9seg_trajectory(mode):
+    """BASELINE config 5 family without the DCN swap: C3k2 + GAM + SPPF backbone, v9 head"""
+    import yolo_dual_amd as ydl
+    g = Golden("model_yolov9seg_64")
+    m = ydl.YOLOv9Seg(_cfg("yolov9_seg.yaml", {}))
+    m.img_size = [64, 64]
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode)
 
 
 def test_bf16_tracks_f32():

@@ -318,3 +318,24 @@ def test_model_resnet18seg():
     mk = lambda: {k: (torch.zeros(s) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64))
                   for k, s in shapes.items()}
     _model_check(g, lambda sd, x: R.resnet_seg_forward(sd, x, "basic"), mk, dict(class_weights=None, kind="dice"))
+
+
+def test_model_resnet50seg():
+    """BASELINE config 3 (segment/train.py ResNet50 + SegmentHead)"""
+    from tests.model_shapes import resnet_seg_state_shapes
+    g = Golden("model_resnet50seg_64")
+    shapes = resnet_seg_state_shapes("bottleneck", 12)
+    mk = lambda: {k: (torch.zeros(s) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64))
+                  for k, s in shapes.items()}
+    _model_check(g, lambda sd, x: R.resnet_seg_forward(sd, x, "bottleneck", out_size=(640, 640)), mk,
+                 dict(class_weights=None, kind="dice"))
+
+
+def test_model_yolov9seg():
+    """BASELINE config 5 family (C3k2 + GAM + SPPF backbone); the fixture was generated with `GAM []` because the
+    reference cannot build its own yaml's `GAM [512]` (GAM(c1, 512) is a TypeError)"""
+    import os
+    g = Golden("model_yolov9seg_64")
+    cfg, mk = _yaml_sd(os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg", "yolov9_seg.yaml"), {})
+    _model_check(g, lambda sd, x: R.script_model_forward(sd, cfg, x, (64, 64), family="v9"), mk,
+                 dict(class_weights=CW, kind="dice"))

@@ -316,19 +316,26 @@ class _ResNetSeg(YdlModule):
             raise NotImplementedError("test-time augmentation is outside the training hot path")
         return run_region(self, [x])
 
+    fixed_out = None        # (H, W) when the reference hard-codes the output size
+
     def _fwd(self, tape: Tape, x: Var) -> Var:
         out = self.head._fwd(tape, self.backbone._fwd(tape, x))
-        if (out.H, out.W) != (x.H, x.W):
-            out = tape.resize(out, x.H, x.W, L.RESIZE_BILINEAR)
+        H, W = self.fixed_out if self.fixed_out is not None else (x.H, x.W)
+        if (out.H, out.W) != (H, W):
+            out = tape.resize(out, H, W, L.RESIZE_BILINEAR)
         return out
 
 
 class ResNet18Seg(_ResNetSeg):
+    """unet-lite/Resnet18/seg_diceloss_resnet18.py:352-403: output resized to the input size"""
     backbone_cls = ResNet18
 
 
 class ResNet50Seg(_ResNetSeg):
+    """segment/train.py:213-250 with its SegmentHead (:159-210), whose forward ends with a hard-coded
+    ``F.interpolate(size=(640, 640), bilinear, align_corners=False)`` whatever the input size"""
     backbone_cls = ResNet50
+    fixed_out = (640, 640)
 
 
 # ----------------------------------------------------------------------------------------------------------
