@@ -5,6 +5,7 @@ layout).  All compute runs in hand-written HIP kernels (libydl_hip.so, C ABI in 
 ATen fallback — importing is cheap, the first GPU call loads the library and fails loudly if it was not built."""
 from . import config
 from .config import compute_dtype, set_compute_dtype
+from .evaluate import ConfusionMatrix
 from .loss import JaccardSegmentationLoss, SegmentationLoss
 from .models import (ResNet18, ResNet18Seg, ResNet50, ResNet50Seg, SegYoloModel, YOLOv5Seg, YOLOv8Seg, YOLOv9Seg,
                      parse_model)
