@@ -38,6 +38,10 @@ struct IgemmArgs {
     int stats_ld;
     unsigned bytesA, bytesB;   // buffer extents for the range-checked loads
     unsigned ldb_bytes;        // byte stride between weight rows (Ttot*Kc*ES when dense)
+    // several output-parity classes in one launch (stride-s dgrad); ncls <= 1: the single-class fields above apply
+    int ncls;
+    int cls_tile0[5];          // first pixel tile of each class (prefix sums), [ncls] = total
+    int cls_ntaps[4], cls_tap0[4], cls_Hg[4], cls_Wg[4], cls_M[4], cls_h0[4], cls_w0[4];
     int grid_n;                // number of output-channel tiles (the grid is 1-D: grid_m * grid_n)
     signed char dh[MAXTAPS], dw[MAXTAPS];
     unsigned char wt[MAXTAPS];
@@ -127,16 +131,27 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
     const int lane = t & 63, wave = t >> 6;
     const int wc = wave % WN, wp = wave / WN;   // channel group / pixel group of this wave
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int mtile = tile / p.grid_n, ntile = tile - mtile * p.grid_n;     // N-tiles of one pixel tile are neighbours
+    int mtile = tile / p.grid_n;
+    const int ntile = tile - mtile * p.grid_n;     // N-tiles of one pixel tile are neighbours
+    // stride-s dgrad: one launch covers all s*s output-parity classes; a pixel tile belongs to ONE class, which selects
+    // its slice of the tap table and its output sub-grid (all values wave-uniform: scalar loads)
+    int c_ntaps = p.ntaps, c_tap0 = 0, c_Hg = p.Hg, c_Wg = p.Wg, c_M = p.M, c_h0 = p.out_h0, c_w0 = p.out_w0;
+    if (p.ncls > 1) {
+        int c = 0;
+        while (c + 1 < p.ncls && mtile >= p.cls_tile0[c + 1]) ++c;
+        mtile -= p.cls_tile0[c];
+        c_ntaps = p.cls_ntaps[c]; c_tap0 = p.cls_tap0[c]; c_Hg = p.cls_Hg[c]; c_Wg = p.cls_Wg[c]; c_M = p.cls_M[c];
+        c_h0 = p.cls_h0[c]; c_w0 = p.cls_w0[c];
+    }
     const int m0 = mtile * BM;
     const int n0 = ntile * BN;
 
     if (t < MAXTAPS) {
         int da = 0, db = 0, dd = 0;
-        if (t < p.ntaps) {
-            da = ((int)p.dh[t] * p.Wi + (int)p.dw[t]) * p.lda * ES;
-            db = (int)p.wt[t] * p.Kc * ES;
-            dd = ((int)p.dh[t] & 0xffff) | ((int)p.dw[t] << 16);
+        if (t < c_ntaps) {
+            da = ((int)p.dh[c_tap0 + t] * p.Wi + (int)p.dw[c_tap0 + t]) * p.lda * ES;
+            db = (int)p.wt[c_tap0 + t] * p.Kc * ES;
+            dd = ((int)p.dh[c_tap0 + t] & 0xffff) | ((int)p.dw[c_tap0 + t] << 16);
         }
         sTapA[t] = da;
         sTapB[t] = db;
@@ -153,11 +168,11 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         rowoff[i] = 0;
         ih0[i] = -100000;          // tail rows: every tap fails the range test => zeros
         iw0[i] = 0;
-        if (m < p.M) {
-            int gw = m % p.Wg;
-            int tmp = m / p.Wg;
-            int gh = tmp % p.Hg;
-            int n = tmp / p.Hg;
+        if (m < c_M) {
+            int gw = m % c_Wg;
+            int tmp = m / c_Wg;
+            int gh = tmp % c_Hg;
+            int n = tmp / c_Hg;
             ih0[i] = gh * p.in_mul;
             iw0[i] = gw * p.in_mul;
             rowoff[i] = (unsigned)(((n * p.Hi + ih0[i]) * p.Wi + iw0[i]) * p.lda) * (unsigned)ES;
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         browoff[i] = (unsigned)co * p.ldb_bytes;
     }
     const int cpt = p.Kc / V;                       // chunks per tap
-    const int nchunks = p.ntaps * cpt;
+    const int nchunks = c_ntaps * cpt;
     const int nk = (nchunks + 7) >> 3;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
@@ -287,12 +302,12 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             int m = m0 + wp * (BM / WP) + j * 16 + lrow;
-            if (m < p.M) {
-                int gw = m % p.Wg;
-                int tmp = m / p.Wg;
-                int gh = tmp % p.Hg;
-                int n = tmp / p.Hg;
-                size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + p.out_h0)) * p.Wo + (gw * p.out_mul + p.out_w0);
+            if (m < c_M) {
+                int gw = m % c_Wg;
+                int tmp = m / c_Wg;
+                int gh = tmp % c_Hg;
+                int n = tmp / c_Hg;
+                size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
                 const T* src = Cg + pix * p.ldc;
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
@@ -321,12 +336,12 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         int m = m0 + wp * (BM / WP) + j * 16 + lrow;
-        if (m < p.M) {
-            int gw = m % p.Wg;
-            int tmp = m / p.Wg;
-            int gh = tmp % p.Hg;
-            int n = tmp / p.Hg;
-            size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + p.out_h0)) * p.Wo + (gw * p.out_mul + p.out_w0);
+        if (m < c_M) {
+            int gw = m % c_Wg;
+            int tmp = m / c_Wg;
+            int gh = tmp % c_Hg;
+            int n = tmp / c_Hg;
+            size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
             T* dst = Cg + pix * p.ldc;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         constexpr int NV = 4 * CT;
         float* red = (float*)smem;             // [4][BN]; safe: all LDS reads finished at the last barrier
         float* smean = red + WP * BN;          // [BN]
-        const int nvalid = min(BM, p.M - m0);
+        const int nvalid = min(BM, c_M - m0);
         const int lgrp = lane >> 4;
         float v[NV];
 #pragma unroll
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
                 for (int j = 0; j < PT; ++j) {
                     int m = m0 + wp * (BM / WP) + j * 16 + lrow;
                     float d = acc[c][j][e] - mu;
-                    t2 += (m < p.M) ? d * d : 0.f;
+                    t2 += (m < c_M) ? d * d : 0.f;
                 }
                 v[c * 4 + e] = t2;
             }
@@ -627,6 +642,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 
 struct PwPlan { bool ok; int RB, CT, WN, NW, block_m, grid_m; size_t smem; };
 static int g_pw_enabled = 1;
+static int g_dgrad_merge = 1;
 static int device_cus() {
     static int cus = 0;
     if (cus == 0) {
@@ -698,7 +714,14 @@ static bool args_pointwise(const IgemmArgs& a) {
 template <typename T, int BM, int BN, int NW = 4, int WP = 4>
 static int launch_igemm(IgemmArgs a, hipStream_t st) {
     a.grid_n = (a.Cst + BN - 1) / BN;
-    dim3 grid(((a.M + BM - 1) / BM) * a.grid_n);
+    int mtiles = (a.M + BM - 1) / BM;
+    if (a.ncls > 1) {
+        int acc = 0;
+        for (int c = 0; c < a.ncls; ++c) { a.cls_tile0[c] = acc; acc += (a.cls_M[c] + BM - 1) / BM; }
+        a.cls_tile0[a.ncls] = acc;
+        mtiles = acc;
+    }
+    dim3 grid(mtiles * a.grid_n);
     size_t smem = 2 * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
@@ -843,42 +866,83 @@ extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy,
     YDL_CHECK(g->ldy >= round_up(g->Cout, 8), "dy pixel stride must cover Cout rounded up to 8");
     hipStream_t st = (hipStream_t)stream;
     const int s = g->s, k = g->k, pd = g->p;
+    // dx[h] gets dy[(h + p - r)/s] * w[r] for taps r with (h + p - r) % s == 0: per output-parity class (ph, pw) a dense
+    // convolution over its own tap subset (no zero MACs).  All classes run in ONE launch (a pixel tile belongs to one
+    // class; heavier classes first): four separate launches each paid their own tail and launch gap.
+    struct Cls { int ph, pw, nt, Hg, Wg; signed char dh[MAXTAPS], dw[MAXTAPS]; unsigned char wt[MAXTAPS]; };
+    static thread_local Cls cls[16];
+    int ncls = 0, total_taps = 0;
+    YDL_CHECK(s * s <= 16, "stride too large for the dgrad class table");
     for (int ph = 0; ph < s; ++ph)
         for (int pw = 0; pw < s; ++pw) {
-            IgemmArgs a{};
-            a.A = dy; a.B = wt; a.C = dx; a.stats = nullptr;
-            a.N = g->N; a.Hi = g->Ho; a.Wi = g->Wo; a.lda = g->ldy;
-            a.Kc = round_up(g->Cout, 8);
-            a.Ho = g->Hi; a.Wo = g->Wi; a.ldc = g->ldx; a.Cout = g->Cin;
-            a.Cst = g->Cin;
-            a.Hg = (g->Hi - ph + s - 1) / s; a.Wg = (g->Wi - pw + s - 1) / s;
-            if (a.Hg <= 0 || a.Wg <= 0) continue;
-            a.in_mul = 1; a.out_mul = s; a.out_h0 = ph; a.out_w0 = pw;
-            a.Ttot = k * k; a.accumulate = accumulate;
-            a.M = g->N * a.Hg * a.Wg;
+            Cls& c = cls[ncls];
+            c.ph = ph; c.pw = pw;
+            c.Hg = (g->Hi - ph + s - 1) / s; c.Wg = (g->Wi - pw + s - 1) / s;
+            if (c.Hg <= 0 || c.Wg <= 0) continue;
             int nt = 0;
-            // dx[h] gets dy[(h + p - r)/s] * w[r] for taps r with (h + p - r) % s == 0
             for (int r = 0; r < k; ++r) {
                 int nh = ph + pd - r;
                 if (((nh % s) + s) % s != 0) continue;
-                for (int c = 0; c < k; ++c) {
-                    int nw = pw + pd - c;
+                for (int cc = 0; cc < k; ++cc) {
+                    int nw = pw + pd - cc;
                     if (((nw % s) + s) % s != 0) continue;
                     int dh = nh >= 0 ? nh / s : -((-nh) / s), dw = nw >= 0 ? nw / s : -((-nw) / s);
-                    a.dh[nt] = (signed char)dh; a.dw[nt] = (signed char)dw; a.wt[nt] = (unsigned char)(r * k + c);
+                    c.dh[nt] = (signed char)dh; c.dw[nt] = (signed char)dw; c.wt[nt] = (unsigned char)(r * k + cc);
                     ++nt;
                 }
             }
-            a.ntaps = nt;
-            int e = 0;
-            if (nt == 0) {
-                // no tap reaches this parity class (k < s): the gradient there is zero
-                a.ntaps = 0;
-            }
-            if (int e2 = set_extents(a, dtype)) return e2;
-            e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
-            if (e) return e;
+            c.nt = nt;                       // nt == 0 (k < s): the gradient of this class is zero, the kernel stores zeros
+            total_taps += nt;
+            ++ncls;
         }
+    auto base_args = [&]() {
+        IgemmArgs a{};
+        a.A = dy; a.B = wt; a.C = dx; a.stats = nullptr;
+        a.N = g->N; a.Hi = g->Ho; a.Wi = g->Wo; a.lda = g->ldy;
+        a.Kc = round_up(g->Cout, 8);
+        a.Ho = g->Hi; a.Wo = g->Wi; a.ldc = g->ldx; a.Cout = g->Cin;
+        a.Cst = g->Cin;
+        a.in_mul = 1; a.out_mul = s;
+        a.Ttot = k * k; a.accumulate = accumulate;
+        return a;
+    };
+    if (g_dgrad_merge && ncls > 1 && ncls <= 4 && total_taps <= MAXTAPS) {
+        // heavier classes first (their CTAs run longest)
+        int order[4] = {0, 1, 2, 3};
+        for (int i = 0; i < ncls; ++i)
+            for (int j = i + 1; j < ncls; ++j)
+                if (cls[order[j]].nt > cls[order[i]].nt) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+        IgemmArgs a = base_args();
+        a.ncls = ncls;
+        int tp = 0, maxM = 0;
+        for (int i = 0; i < ncls; ++i) {
+            const Cls& c = cls[order[i]];
+            a.cls_ntaps[i] = c.nt; a.cls_tap0[i] = tp; a.cls_Hg[i] = c.Hg; a.cls_Wg[i] = c.Wg;
+            a.cls_M[i] = g->N * c.Hg * c.Wg; a.cls_h0[i] = c.ph; a.cls_w0[i] = c.pw;
+            for (int t = 0; t < c.nt; ++t) { a.dh[tp + t] = c.dh[t]; a.dw[tp + t] = c.dw[t]; a.wt[tp + t] = c.wt[t]; }
+            tp += c.nt;
+            if (a.cls_M[i] > maxM) maxM = a.cls_M[i];
+        }
+        // single-class fields: used for the tile choice (M of the largest class) and as defaults
+        a.Hg = a.cls_Hg[0]; a.Wg = a.cls_Wg[0]; a.out_h0 = a.cls_h0[0]; a.out_w0 = a.cls_w0[0];
+        a.ntaps = a.cls_ntaps[0];
+        a.M = 0;
+        for (int i = 0; i < ncls; ++i) a.M += a.cls_M[i];       // tile choice sees the whole launch
+        (void)maxM;
+        if (int e2 = set_extents(a, dtype)) return e2;
+        return dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
+    }
+    for (int ci = 0; ci < ncls; ++ci) {
+        const Cls& c = cls[ci];
+        IgemmArgs a = base_args();
+        a.Hg = c.Hg; a.Wg = c.Wg; a.out_h0 = c.ph; a.out_w0 = c.pw;
+        a.M = g->N * a.Hg * a.Wg;
+        a.ntaps = c.nt;
+        for (int t = 0; t < c.nt; ++t) { a.dh[t] = c.dh[t]; a.dw[t] = c.dw[t]; a.wt[t] = c.wt[t]; }
+        if (int e2 = set_extents(a, dtype)) return e2;
+        int e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
+        if (e) return e;
+    }
     return 0;
 }
 
@@ -1291,10 +1355,12 @@ static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, 
 
 static int g_wgrad_tr = 1;
 // debug knobs: key 0 = bf16 wgrad path: 1 (default) 128-wide tr-read kernel, 2 64x64 tr-read kernel, 0 64x64 scalar-LDS-read kernel
+//              key 2 = strided dgrad: 1 (default) all output-parity classes in one launch, 0 one launch per class
 //              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
 extern "C" void ydl_debug_set(int key, int val) {
     if (key == 0) g_wgrad_tr = val;
     if (key == 1) g_pw_enabled = val;
+    if (key == 2) g_dgrad_merge = val;
 }
 
 extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream) {
