@@ -24,7 +24,14 @@ def round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> ctypes.c_void_p:
+    """hipStream_t of torch's current stream (the raw accessor is ~20x cheaper than building a Stream object, and this is
+    called once per kernel launch)"""
+    if _RAW_STREAM is not None:
+        return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -340,7 +347,18 @@ class Tape:
         es = w.element_size()
         Cin_p, Cout_p = round_up(Cin, 8), round_up(Cout, 8)
         if virt is None:
-            geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld, 0)
+            gkey = (x.N, x.H, x.W, Cin, Cout, k, s, p, x.ld, y.ld, self.dt)
+            gc = getattr(m, "_geom_cache", None)
+            if gc is None or gc[0] != gkey:
+                geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld, 0)
+                gpp = ctypes.byref(geom)
+                gc = (gkey, geom, L.lib().ydl_conv_fwd_stats_ws_bytes(gpp, self.dt), L.lib().ydl_conv_fwd_grid_m(gpp, self.dt),
+                      L.lib().ydl_conv_fwd_block_m(gpp, self.dt))
+                try:
+                    m._geom_cache = gc
+                except Exception:
+                    pass
+            geom = gc[1]
             subs = None
         else:
             # one sub-convolution per source, on column block [c0, c0+C) of the weight matrix (row stride = Cin_p)
@@ -372,10 +390,14 @@ class Tape:
                 first = False
 
         if self.train:
-            nbytes = L.lib().ydl_conv_fwd_stats_ws_bytes(gp, self.dt)
+            if subs is None:
+                nbytes, grid_m, block_m = gc[2], gc[3], gc[4]
+            else:
+                nbytes = L.lib().ydl_conv_fwd_stats_ws_bytes(gp, self.dt)
+                grid_m, block_m = L.lib().ydl_conv_fwd_grid_m(gp, self.dt), L.lib().ydl_conv_fwd_block_m(gp, self.dt)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
             conv_fwd(_p(ws))
-            L.call("ydl_bn_finalize", _p(ws), L.lib().ydl_conv_fwd_grid_m(gp, self.dt), L.lib().ydl_conv_fwd_block_m(gp, self.dt),
+            L.call("ydl_bn_finalize", _p(ws), grid_m, block_m,
                    npix, Cout, _p(m.bn.weight), _p(m.bn.bias), m.bn.eps, m.bn.momentum,
                    _p(m.bn.running_mean), _p(m.bn.running_var), _p(cf["mean"]), _p(cf["invstd"]),
                    _p(cf["scale"]), _p(cf["shift"]), rep, st)
