@@ -111,3 +111,50 @@ def test_short_training_run_tracks_the_oracle(oracle_result, mode, loss_tol, mio
     assert worst <= loss_tol, (mode, worst, losses[-3:], ref_losses[-3:])
     assert ref_losses[-1] < ref_losses[0], "the run must actually train"
     assert abs(miou - ref_miou) <= miou_tol, (mode, miou, ref_miou)
+
+
+@pytest.mark.parametrize("hw,bs", [((95, 81), 1), ((64, 96), 3), ((160, 128), 2)])
+def test_ragged_input_sizes_match_the_oracle(hw, bs):
+    """odd / non-square inputs and batch 1 through the whole yolov5 model in parity mode: every layer size becomes ragged
+    (odd strides-2 outputs, bilinear concat alignment between unequal maps, the stem falls back from the space-to-depth
+    form when a side is odd), forward logits, loss and the gradient of every live parameter against the CPU oracle"""
+    import yolo_dual_amd as ydl
+    from tests.util import l2_err, rel_err
+    cfg = _cfg()
+    H, W = hw
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.rand(bs, 3, H, W).astype(np.float32))
+    t = torch.from_numpy(rs.randint(0, 12, size=(bs, H, W)).astype(np.int64))
+    shapes = script_model_state_shapes(cfg)
+    sd = {k: (torch.zeros(s) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64))
+          for k, s in shapes.items()}
+    fill_state_dict(sd, 21, bn_stats=False)
+    pnames = [k for k in sd if k.endswith(".weight") or k.endswith(".bias")]
+    ps = {k: sd[k].detach().clone().requires_grad_(True) for k in pnames}
+    run = dict(sd)
+    run.update(ps)
+    out = R.script_model_forward(run, cfg, x, (H, W))
+    total, _, _ = R.seg_loss(out, t, CW, "dice")
+    total.backward()
+    ydl.set_compute_dtype("f32")
+    try:
+        m = ydl.YOLOv5Seg(cfg)
+        m.img_size = [H, W]
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        crit = ydl.SegmentationLoss(12, 0.0, CW, "dice")
+        o2 = m(x.cuda())
+        tot2, items = crit(o2, t.cuda())
+        tot2.backward()
+        assert list(o2.shape) == list(out.shape)
+        assert rel_err(o2.detach().cpu(), out.detach()) < 1e-4
+        assert abs(items[0] - float(total)) <= 1e-4 * abs(float(total))
+        named = dict(m.named_parameters())
+        none_ref = sorted(k for k in pnames if ps[k].grad is None)
+        none_got = sorted(k for k, p in named.items() if not getattr(p, "_ydl_touched", False))
+        assert none_got == none_ref
+        bad = {k: l2_err(named[k].grad.detach().cpu(), ps[k].grad) for k in pnames
+               if ps[k].grad is not None and l2_err(named[k].grad.detach().cpu(), ps[k].grad) > 2e-3}
+        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+    finally:
+        ydl.set_compute_dtype("bf16")
