@@ -1305,7 +1305,8 @@ static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, 
     a.M = g->N * g->Ho * g->Wo;
     unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * 2ull;
     unsigned long long by = (unsigned long long)a.M * g->ldy * 2ull;
-    YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M < (1ull << 21),
+    // pixel decode by multiply-shift with magic = ceil(2^40 / d), d <= Ho*Wo: exact for every n <= M while M * d < 2^40
+    YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M * ((unsigned long long)g->Ho * g->Wo) < (1ull << 40),
               "tensor too large for the 32-bit wgrad addressing");
     a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by;
     a.magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
@@ -1378,7 +1379,8 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     {
         unsigned long long es = (unsigned long long)esize(dtype);
         unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * es, by = (unsigned long long)a.M * g->ldy * es;
-        YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M < (1ull << 21),
+        // pixel decode by multiply-shift with magic = ceil(2^40 / d), d <= Ho*Wo: exact for every n <= M while M * d < 2^40
+    YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M * ((unsigned long long)g->Ho * g->Wo) < (1ull << 40),
                   "tensor too large for the 32-bit wgrad addressing");
         a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by;
         a.magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
@@ -1410,7 +1412,7 @@ extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, 
     // measured on MI355X: the 128-wide pipelined kernel wins on the large-M layers (>= 160x160 at bs 16), the small
     // 64x64-tile kernel (8 CTAs/CU) wins where M is small and the grid of big tiles would be latency-bound
     static const int wg2_min_m = getenv("YDL_WG2_MINM") ? atoi(getenv("YDL_WG2_MINM")) : 200000;
-    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && a.M >= wg2_min_m && a.M < (1 << 21)) return launch_wgrad2(g, x, dy, dw, st);
+    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && a.M >= wg2_min_m) return launch_wgrad2(g, x, dy, dw, st);
     if (dtype == YDL_F32) wgrad_kernel<float, false><<<grid, 256, 0, st>>>(a);
     else if (g_wgrad_tr) wgrad_kernel<bf16_t, true><<<grid, 256, 0, st>>>(a);
     else wgrad_kernel<bf16_t, false><<<grid, 256, 0, st>>>(a);
