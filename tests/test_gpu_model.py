@@ -464,3 +464,32 @@ def test_config3_size_resnet50():
         opt.step()
         losses.append(float(items[0]))
     assert losses[-1] < losses[0], losses
+
+
+def test_config5_size_yolov9():
+    """BASELINE config 5 family at its full per-GPU size (YOLOv9 C3k2 + GAM + SPPF backbone, 640x640, bs=16; the DCN
+    variants of its blocks are parity-unpinned and not built): same size-independent checks"""
+    import yolo_dual_amd as ydl
+    ydl.set_compute_dtype("bf16")
+    m = ydl.YOLOv9Seg(_cfg("yolov9_seg.yaml", {})).cuda().train()
+    opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.937, weight_decay=5e-4)
+    crit = ydl.SegmentationLoss(12, 0.0, CW, "dice")
+    gen = torch.Generator("cuda").manual_seed(0)
+    x = torch.rand(16, 3, 640, 640, device="cuda", generator=gen)
+    t = torch.randint(0, 12, (16, 640, 640), device="cuda", generator=gen)
+    losses = []
+    for st in range(3):
+        opt.zero_grad()
+        out = m(x)
+        assert out.shape == (16, 12, 640, 640)
+        total, items = crit(out, t)
+        assert np.isfinite(items).all()
+        total.backward()
+        if st == 0:
+            for k, p in m.named_parameters():
+                if getattr(p, "_ydl_touched", False):
+                    gn = float(p.grad.float().norm())
+                    assert np.isfinite(gn) and gn > 0, k
+        opt.step()
+        losses.append(float(items[0]))
+    assert losses[-1] < losses[0], losses
