@@ -40,8 +40,16 @@ enum { YDL_LOSS_DICE = 0, YDL_LOSS_JACCARD = 1 };
 
 const char* ydl_last_error(void);
 int ydl_version(void);
-/* debug knobs for A/B tests: key 0 = wgrad transposed-LDS-read path on (1, default) / off (0) */
+/* Test-only, process-wide debug knobs for A/B tests (key 0: bf16 wgrad operand path, 1: streaming point-wise kernel on/off,
+ * 2: strided dgrad in one launch / per class).  They change launch geometry: a caller that caches ydl_conv_fwd_grid_m /
+ * _block_m / _stats_ws_bytes must drop its cache after a change.  Everything else in the library is per call or per
+ * device (kernel attributes and the CU count are keyed by the HIP device id current at the call). */
 void ydl_debug_set(int key, int val);
+/* diagnostics: number of (kernel, device) launch-attribute initialisations done so far */
+int ydl_debug_attr_sets(void);
+/* diagnostics: name of the kernel instantiation the last call of an entry family launched (process-wide);
+ * family 0 ydl_conv_fwd, 1 ydl_conv_dgrad, 2 ydl_conv_wgrad, 3 ydl_bn_finalize.  "" if none yet. */
+const char* ydl_debug_last_kernel(int family);
 
 /* ---- convolution as implicit GEMM on MFMA ------------------------------------------------------------
  * Geometry of one conv layer (square kernel k, stride s, padding p, groups=1, no bias).
@@ -75,6 +83,11 @@ int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void
 /* dw[Cout][k*k][Cin_p] (f32) += sum over pixels dy^T * im2col(x).  dw must be zeroed (or hold the running
  * sum for gradient accumulation) before the call: split-K blocks add with f32 atomics. */
 int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream);
+/* Deterministic form (bitwise reproducible from run to run): every split-K block stores its partial tile into
+ * ws = [splits][Cout][k*k*Cin_p] f32 (ydl_conv_wgrad_ws_bytes) and a second kernel adds the partials into dw in a fixed
+ * order.  Same products and tiles as ydl_conv_wgrad; parity mode (YDL_F32) uses it by default. */
+int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype);
+int ydl_conv_wgrad_det(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, float* ws, void* stream);
 
 /* master weights (f32, KRSC [Cout][k*k][Cin]) -> compute copies: w [Cout][kk][Cin_p] and wt [Cin][kk][Cout_p] */
 int ydl_weight_prep(int dtype, const float* master, void* w, void* wt, int Cout, int kk, int Cin, void* stream);

@@ -1,0 +1,202 @@
+"""The kernel instantiations that produce the benchmark number, pinned to the CPU oracle.
+
+The golden/oracle block tests run at C <= 32 and H <= 36, where the launcher always picks the 64-pixel tiles.  Here ONE
+``ydl.Conv`` (conv -> train-mode BN -> SiLU, seg_diceloss_yolov5.py:388-409) runs forward + backward at shapes that select
+every instantiation on the benchmark's hot path — the 128-pixel implicit-GEMM tiles (3x3 and wide 1x1, 4 and 8 waves), the
+weight-stationary point-wise streaming kernel for every K-row width, the strided one-launch dgrad, the 128-wide pipelined
+weight-gradient kernel (M >= 200 000 pixels), deep split-K, and the two-level BN-statistics merge (> 1024 partial rows) —
+and is compared with ``oracle.ref_cpu.conv_bn_act`` (pinned to the reference by tests/golden) on the same inputs.  Which
+kernel ran is asserted through ``ydl_debug_last_kernel``.
+
+Tolerances: f32 parity mode — output 1e-4, gradients 5e-4 (max-abs relative), as tests/test_gpu_blocks.py; bf16 throughput
+mode — the oracle is run on the bf16-rounded input and weights, output 2e-2 and gradients 3e-2 in relative L2 (bf16 storage
+of y / out / dy has 8 mantissa bits; a wrong tile index would give O(1))."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.util import l2_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(mode, N, c1, c2, k, s, H, W, seed=0, act=True):
+    """run Conv(c1, c2, k, s) fwd+bwd on the HIP path and on the CPU oracle; returns (got, ref, kernels)"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    ydl.set_compute_dtype(mode)
+    try:
+        rs = np.random.RandomState(seed)
+        fan_in = c1 * k * k
+        w = torch.from_numpy((rs.standard_normal((c2, c1, k, k)) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+        gamma = torch.from_numpy(rs.uniform(0.5, 1.5, c2).astype(np.float32))
+        beta = torch.from_numpy(rs.uniform(-0.3, 0.3, c2).astype(np.float32))
+        x = torch.from_numpy((rs.standard_normal((N, c1, H, W)) + 0.25).astype(np.float32))
+        if mode == "bf16":          # both sides see the same (bf16-representable) operands
+            w = w.bfloat16().float()
+            x = x.bfloat16().float()
+        m = ydl.Conv(c1, c2, k, s, None, 1, act)
+        with torch.no_grad():
+            m.conv.weight.copy_(w)
+            m.bn.weight.copy_(gamma)
+            m.bn.bias.copy_(beta)
+        m = m.cuda().train()
+        xg = x.cuda().requires_grad_(True)
+        out = m(xg)
+        Ho, Wo = out.shape[2:]
+        gup = torch.from_numpy(rs.standard_normal((N, c2, Ho, Wo)).astype(np.float32))
+        (out * gup.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        kern = {f: L.last_kernel(i) for i, f in enumerate(("fwd", "dgrad", "wgrad", "bn_finalize"))}
+        got = dict(out=out.detach().cpu(), dx=xg.grad.detach().cpu(), dw=m.conv.weight.grad.detach().float().cpu(),
+                   dgamma=m.bn.weight.grad.detach().cpu(), dbeta=m.bn.bias.grad.detach().cpu(),
+                   rm=m.bn.running_mean.detach().cpu(), rv=m.bn.running_var.detach().cpu())
+        # CPU oracle
+        torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+        sd = {"c.conv.weight": w.clone().requires_grad_(True), "c.bn.weight": gamma.clone().requires_grad_(True),
+              "c.bn.bias": beta.clone().requires_grad_(True), "c.bn.running_mean": torch.zeros(c2),
+              "c.bn.running_var": torch.ones(c2)}
+        xr = x.clone().requires_grad_(True)
+        o = R.conv_bn_act(sd, "c", xr, s=s, p=None, act="silu" if act else "none")
+        (o * gup).sum().backward()
+        ref = dict(out=o.detach(), dx=xr.grad, dw=sd["c.conv.weight"].grad, dgamma=sd["c.bn.weight"].grad,
+                   dbeta=sd["c.bn.bias"].grad, rm=sd["c.bn.running_mean"], rv=sd["c.bn.running_var"])
+        return got, ref, kern
+    finally:
+        ydl.set_compute_dtype("bf16")
+
+
+def _check(got, ref, mode, tag):
+    if mode == "f32":
+        assert rel_err(got["out"], ref["out"]) < 1e-4, (tag, "out", rel_err(got["out"], ref["out"]))
+        for k in ("dx", "dw", "dgamma", "dbeta"):
+            assert rel_err(got[k], ref[k]) < 5e-4, (tag, k, rel_err(got[k], ref[k]))
+        for k in ("rm", "rv"):
+            assert rel_err(got[k], ref[k]) < 1e-4, (tag, k, rel_err(got[k], ref[k]))
+    else:
+        assert l2_err(got["out"], ref["out"]) < 2e-2, (tag, "out", l2_err(got["out"], ref["out"]))
+        for k in ("dx", "dw", "dgamma", "dbeta"):
+            assert l2_err(got[k], ref[k]) < 3e-2, (tag, k, l2_err(got[k], ref[k]))
+        for k in ("rm", "rv"):
+            assert rel_err(got[k], ref[k]) < 1e-3, (tag, k, rel_err(got[k], ref[k]))   # statistics come from f32 accumulators
+
+
+# (tag, mode, N, c1, c2, k, s, H, W, expected substrings of the fwd / dgrad / wgrad / bn_finalize kernel names)
+TILED = [
+    # 128x128 tile, 8 waves: the 3x3 layers of the 80x80 / 40x40 stages at bs 16 select it; same tile at bs 4 @160
+    ("k3_128x128_f32", "f32", 4, 128, 128, 3, 1, 160, 160, ("igemm_kernel<f32,128,128,8", "igemm_kernel<f32,128,128,8", "wgrad_kernel<f32>", "")),
+    ("k3_128x64_f32", "f32", 4, 64, 64, 3, 1, 160, 160, ("igemm_kernel<f32,128,64,4", "igemm_kernel<f32,128,64,4", "wgrad_kernel<f32>", "")),
+    ("k3_512_40_f32", "f32", 16, 512, 512, 3, 1, 40, 40, ("igemm_kernel<f32,128,128,8", "igemm_kernel<f32,128,128,8", "wgrad_kernel<f32>", "")),
+    # stride-2 down-sampler: forward gathers with in_mul 2, dgrad = 4 output-parity classes in one launch
+    ("k3s2_128_256_f32", "f32", 4, 128, 256, 3, 2, 160, 160, ("igemm_kernel<f32,128,64,4", "igemm_kernel<f32,128,128,8", "wgrad_kernel<f32>", "")),
+    # small-M deep layer: 64-pixel / 64-channel tiles
+    ("k1_1024_20_f32", "f32", 16, 1024, 1024, 1, 1, 20, 20, ("igemm_kernel<f32,128,64,4", "igemm_kernel<f32,128,64,4", "wgrad_kernel<f32>", "")),
+    # bf16: the throughput-mode instantiations of the same tiles
+    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm_kernel<bf16,128,128,8", "igemm_kernel<bf16,128,128,8", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm_kernel<bf16,128,128,8", "wgrad_kernel<bf16,tr>", "")),
+    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm_kernel<bf16,128,128,8", "igemm_kernel<bf16,128,64,4", "wgrad_kernel<bf16,tr>", "")),
+]
+
+
+@pytest.mark.parametrize("case", TILED, ids=[c[0] for c in TILED])
+def test_tiled_igemm_hot_instantiations(case):
+    tag, mode, N, c1, c2, k, s, H, W, exp = case
+    got, ref, kern = _case(mode, N, c1, c2, k, s, H, W)
+    for fam, e in zip(("fwd", "dgrad", "wgrad", "bn_finalize"), exp):
+        assert kern[fam].startswith(e), (tag, fam, kern[fam], "expected", e)
+    _check(got, ref, mode, tag)
+
+
+# point-wise streaming kernel: K-row widths 128 / 256 / 512 bytes, 64 / 128 / 256 output channels, M >= 65 536 pixels
+PW = [
+    ("pw_rb128_f32", "f32", 4, 32, 128, "pw_kernel<f32,128,8,4>"),
+    ("pw_rb256_f32", "f32", 4, 64, 128, "pw_kernel<f32,256,8,4>"),
+    ("pw_rb512_ct4_f32", "f32", 4, 128, 64, "pw_kernel<f32,512,4,4>"),
+    ("pw_rb512_nw8_f32", "f32", 4, 128, 128, "pw_kernel<f32,512,8,8>"),
+    ("pw_rb128_bf16", "bf16", 4, 64, 128, "pw_kernel<bf16,128,8,4>"),
+    ("pw_rb256_bf16", "bf16", 4, 128, 128, "pw_kernel<bf16,256,8,4>"),
+    ("pw_rb256_c256_bf16", "bf16", 4, 128, 256, "pw_kernel<bf16,256,8,4>"),
+    ("pw_rb512_bf16", "bf16", 4, 256, 64, "pw_kernel<bf16,512,4,4>"),
+]
+
+
+@pytest.mark.parametrize("case", PW, ids=[c[0] for c in PW])
+def test_pointwise_streaming_kernel_against_oracle(case):
+    tag, mode, N, c1, c2, expk = case
+    got, ref, kern = _case(mode, N, c1, c2, 1, 1, 160, 160)
+    assert kern["fwd"] == expk, (tag, kern)
+    # the input gradient of a 1x1 conv is a 1x1 conv with Cin <-> Cout: also the streaming kernel when it qualifies
+    _check(got, ref, mode, tag)
+
+
+@pytest.mark.parametrize("c1,c2,k,expk", [(128, 128, 1, "wgrad2_kernel<128>"), (128, 64, 3, "wgrad2_kernel<64>"),
+                                          (64, 128, 3, "wgrad2_kernel<128>")])
+def test_wgrad2_pipelined_kernel_against_oracle(c1, c2, k, expk):
+    """bf16, M = 8*160*160 = 204 800 >= 200 000 pixels: the 128-wide register-pipelined weight-gradient kernel"""
+    got, ref, kern = _case("bf16", 8, c1, c2, k, 1, 160, 160)
+    assert kern["wgrad"] == expk, kern
+    _check(got, ref, "bf16", expk)
+
+
+def test_bn_finalize_two_level_merge_against_oracle():
+    """> 1024 per-block partial rows (147 456 pixels / 128): the level-1 pre-merge of ydl_bn_finalize"""
+    got, ref, kern = _case("f32", 4, 16, 32, 3, 1, 192, 192)
+    assert kern["bn_finalize"] == "bn_finalize<two-level>", kern
+    _check(got, ref, "f32", "bn_two_level")
+
+
+def test_parity_mode_weight_gradient_is_bitwise_reproducible():
+    """YDL_F32 uses the deterministic split-K (partial slabs + fixed-order sum): two runs give identical bits, also with the
+    weight-gradient kernels on the second stream (a cross-stream race would show up here as well)"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
+    assert config.deterministic("f32") and not config.deterministic("bf16")
+    res = []
+    for _ in range(3):
+        got, _ref, _k = _case("f32", 2, 64, 96, 3, 1, 96, 104, seed=3)
+        res.append(got)
+    for k in ("out", "dx", "dw", "dgamma", "dbeta"):
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+    # the atomic form of the same kernels agrees to rounding (same products, arrival-order sums)
+    config.set_deterministic(False)
+    try:
+        got2, _ref, _k = _case("f32", 2, 64, 96, 3, 1, 96, 104, seed=3)
+    finally:
+        config.set_deterministic(None)
+    assert rel_err(got2["dw"], res[0]["dw"]) < 1e-5
+    # and the deterministic form of the bf16 kernels (incl. the 128-wide pipelined one) against their atomic form
+    config.set_deterministic(True)
+    try:
+        a, _r, ka = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
+        b, _r, _kb = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
+    finally:
+        config.set_deterministic(None)
+    assert ka["wgrad"].startswith("wgrad2_kernel")
+    assert torch.equal(a["dw"], b["dw"])
+    c, _r, _kc = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
+    assert rel_err(c["dw"], a["dw"]) < 1e-4
+
+
+def test_launch_attributes_are_set_per_device():
+    """kernel attributes (> 64 KB dynamic LDS) are keyed by the HIP device id: the first launch of an instantiation on a device
+    registers it once; repeated launches on the same device do not"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    ydl.set_compute_dtype("bf16")
+    m = ydl.Conv(128, 128, 3, 1).cuda().train()
+    x = torch.randn(2, 128, 96, 96, device="cuda")
+    m(x)
+    torch.cuda.synchronize()
+    n1 = L.lib().ydl_debug_attr_sets()
+    assert n1 >= 1
+    m(x)
+    torch.cuda.synchronize()
+    assert L.lib().ydl_debug_attr_sets() == n1
+    if torch.cuda.device_count() > 1:
+        with torch.cuda.device(1):
+            m1 = ydl.Conv(128, 128, 3, 1).to("cuda:1").train()
+            out = m1(x.to("cuda:1"))
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+        assert L.lib().ydl_debug_attr_sets() > n1

@@ -115,11 +115,13 @@ def test_short_training_run_tracks_the_oracle(oracle_result, mode, loss_tol, mio
     assert abs(miou - ref_miou) <= miou_tol, (mode, miou, ref_miou)
 
 
-@pytest.mark.parametrize("hw,bs", [((95, 81), 1), ((64, 96), 3), ((160, 128), 2)])
+@pytest.mark.parametrize("hw,bs", [((95, 81), 1), ((64, 96), 3), ((160, 128), 2), ((320, 320), 2)])
 def test_ragged_input_sizes_match_the_oracle(hw, bs):
     """odd / non-square inputs and batch 1 through the whole yolov5 model in parity mode: every layer size becomes ragged
     (odd strides-2 outputs, bilinear concat alignment between unequal maps, the stem falls back from the space-to-depth
-    form when a side is odd), forward logits, loss and the gradient of every live parameter against the CPU oracle"""
+    form when a side is odd), forward logits, loss and the gradient of every live parameter against the CPU oracle.
+    320x320 at batch 2 is the whole model at half the benchmark's linear size: its 160x160 / 80x80 layers run the 128-pixel
+    tiles and the point-wise streaming kernel of the benchmark (51 200 ... 204 800 pixels per layer)."""
     import yolo_dual_amd as ydl
     from tests.util import l2_err, rel_err
     cfg = _cfg()

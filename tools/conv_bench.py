@@ -32,8 +32,8 @@ def main():
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many tensor sets (defeats the 256 MB MALL)")
     ap.add_argument("--acc", type=int, default=0, help="dgrad accumulate flag")
     a = ap.parse_args()
-    L.lib().ydl_debug_set(0, a.wg)
-    L.lib().ydl_debug_set(1, a.pw)
+    L.debug_set(0, a.wg)
+    L.debug_set(1, a.pw)
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")

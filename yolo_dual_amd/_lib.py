@@ -30,12 +30,16 @@ SIGNATURES = {
     "ydl_last_error": (C.c_char_p, []),
     "ydl_version": (_i, []),
     "ydl_debug_set": (None, [_i, _i]),
+    "ydl_debug_attr_sets": (_i, []),
+    "ydl_debug_last_kernel": (C.c_char_p, [_i]),
     "ydl_conv_fwd_stats_ws_bytes": (_i64, [_G, _i]),
     "ydl_conv_fwd_grid_m": (_i, [_G, _i]),
     "ydl_conv_fwd_block_m": (_i, [_G, _i]),
     "ydl_conv_fwd": (_i, [_G, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_dgrad": (_i, [_G, _i, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_wgrad": (_i, [_G, _i, _vp, _vp, _vp, _vp]),
+    "ydl_conv_wgrad_ws_bytes": (_i64, [_G, _i]),
+    "ydl_conv_wgrad_det": (_i, [_G, _i, _vp, _vp, _vp, _vp, _vp]),
     "ydl_weight_prep": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ydl_weight_prep_batched": (_i, [_i, _vp, _i, _vp]),
     "ydl_wgrad_unpad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -95,6 +99,24 @@ def lib():
     return _lib
 
 
+_DEBUG_EPOCH = [0]
+
+
+def debug_set(key: int, val: int) -> None:
+    """test-only knobs of the library (ydl.h: ydl_debug_set); bumps an epoch that invalidates cached launch geometry"""
+    lib().ydl_debug_set(key, val)
+    _DEBUG_EPOCH[0] += 1
+
+
+def debug_epoch() -> int:
+    return _DEBUG_EPOCH[0]
+
+
+def last_kernel(family: int) -> str:
+    """name of the kernel instantiation the last call of an entry family launched (0 fwd, 1 dgrad, 2 wgrad, 3 bn_finalize)"""
+    return lib().ydl_debug_last_kernel(family).decode()
+
+
 class YdlError(RuntimeError):
     pass
 
@@ -152,7 +174,7 @@ def call(name: str, *args):
     check(getattr(lib(), name)(*args), name)
     e1.record()
     g = None
-    if name in ("ydl_conv_fwd", "ydl_conv_dgrad", "ydl_conv_wgrad"):
+    if name in ("ydl_conv_fwd", "ydl_conv_dgrad", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
         src = args[0]._obj
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
     _PROFILE.append((name, e0, e1, g))

@@ -6,7 +6,10 @@ import os
 _STATE = {"dtype": "bf16", "weight_epoch": 0, "lazy_upsample": True, "fuse_siblings": True, "overlap_wgrad": os.environ.get("YDL_OVERLAP_WGRAD", "1") != "0",
           "commute_concat": os.environ.get("YDL_COMMUTE_CONCAT", "1") != "0",
           "replicated_loss": os.environ.get("YDL_REPLICATED_LOSS", "1") != "0",
-          "stem_s2d": os.environ.get("YDL_STEM_S2D", "1") != "0"}
+          "stem_s2d": os.environ.get("YDL_STEM_S2D", "1") != "0",
+          # weight gradients: None = deterministic split-K (partial slabs + fixed-order sum) in f32 parity mode, f32 atomics in
+          # bf16 throughput mode; True / False force one form for both
+          "deterministic": {"1": True, "0": False}.get(os.environ.get("YDL_DETERMINISTIC", ""), None)}
 
 
 def set_compute_dtype(name: str) -> None:
@@ -66,6 +69,17 @@ def stem_s2d() -> bool:
 
 def set_stem_s2d(on: bool) -> None:
     _STATE["stem_s2d"] = bool(on)
+
+
+def deterministic(dtype_name: str) -> bool:
+    """weight gradients bitwise reproducible from run to run (ydl_conv_wgrad_det) — default: on in 'f32' parity mode"""
+    d = _STATE["deterministic"]
+    return (dtype_name == "f32") if d is None else bool(d)
+
+
+def set_deterministic(on) -> None:
+    """True / False, or None for the per-dtype default"""
+    _STATE["deterministic"] = None if on is None else bool(on)
 
 
 def replicated_loss() -> bool:

@@ -142,6 +142,7 @@ extern "C" int ydl_bn_finalize(const float* stats_ws, int nblocks, int block_m, 
     hipStream_t st = (hipStream_t)stream;
     const int ldp = round_up(C, 8);
     const float* src = stats_ws;
+    ydl_note_kernel(3, nblocks > 1024 ? "bn_finalize<two-level>" : "bn_finalize<one-level>");
     if (nblocks > 1024) {
         // level 1 writes behind the level-0 partials (the workspace query reserves the room)
         int nchunks = (nblocks + MERGE_CHUNK - 1) / MERGE_CHUNK;

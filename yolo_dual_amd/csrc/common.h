@@ -92,5 +92,25 @@ void ydl_set_error(const std::string& s);
         }                                                                                    \
     } while (0)
 
+// ---- per-device state --------------------------------------------------------------------------------
+// One process may drive several GPUs (the reference's nn.DataParallel does): launch attributes and device properties
+// are kept per HIP device id.  ydl_dev_once(tag) returns true exactly once per (tag, current device) — the caller then
+// sets its kernel attributes for THAT device; ydl_device_cus() is the CU count of the current device.
+#define YDL_MAX_DEVICES 64
+bool ydl_dev_once(void* tag_storage);      // tag_storage: a static std::atomic<uint64_t>-sized word owned by the call site
+int ydl_device_cus();
+void ydl_note_kernel(int family, const char* name);   // diagnostics: last kernel instantiation launched per entry family
+#define YDL_SET_MAX_LDS(kernel, bytes)                                                                              \
+    do {                                                                                                            \
+        static unsigned long long once_ = 0;                                                                        \
+        if (ydl_dev_once(&once_)) {                                                                                 \
+            hipError_t e_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (e_ != hipSuccess) {                                                                                 \
+                ydl_set_error(std::string(__func__) + ": hipFuncSetAttribute failed: " + hipGetErrorString(e_));   \
+                return 2;                                                                                           \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int esize(int dtype) { return dtype == YDL_F32 ? 4 : 2; }

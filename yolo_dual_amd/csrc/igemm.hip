@@ -643,15 +643,6 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 struct PwPlan { bool ok; int RB, CT, WN, NW, block_m, grid_m; size_t smem; };
 static int g_pw_enabled = 1;
 static int g_dgrad_merge = 1;
-static int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        else cus = 256;
-    }
-    return cus;
-}
 // eligibility + launch geometry; a pure function of its arguments (the stats-workspace queries call it too)
 static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) {
     PwPlan pl{};
@@ -669,7 +660,7 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
     // 512-byte rows x 128+ channels need ~230 VGPRs: as 4-wave CTAs that is one wave per SIMD; one 8-wave CTA per CU
     // gives two
     pl.NW = (RB == 512 && pl.CT == 8) ? 8 : 4;
-    const int slots = device_cus() * (pl.NW == 4 ? 2 : 1);
+    const int slots = ydl_device_cus() * (pl.NW == 4 ? 2 : 1);
     int bm = round_up((M + slots - 1) / slots, 16);
     pl.block_m = bm;
     pl.grid_m = (M + bm - 1) / bm;
@@ -680,11 +671,12 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
 }
 
 template <typename T, int RB, int CT, int NW>
-static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pw_kernel<T, RB, CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        attr_set = true;
+static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int fam) {
+    YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW>), 140 * 1024);
+    {
+        static const std::string nm = std::string("pw_kernel<") + (sizeof(T) == 4 ? "f32" : "bf16") + "," + std::to_string(RB) + "," +
+                                      std::to_string(CT) + "," + std::to_string(NW) + ">";
+        ydl_note_kernel(fam, nm.c_str());
     }
     pw_kernel<T, RB, CT, NW><<<pl.grid_m, NW * 64, pl.smem, st>>>(a);
     YDL_LAUNCH_CHECK();
@@ -692,15 +684,15 @@ static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st) {
 }
 
 template <typename T>
-static int launch_pw(const PwArgs& a, const PwPlan& pl, hipStream_t st) {
+static int launch_pw(const PwArgs& a, const PwPlan& pl, hipStream_t st, int fam) {
     if (pl.NW == 8) {
         YDL_CHECK(pl.RB == 512 && pl.CT == 8, "internal: unexpected point-wise plan");
-        return launch_pw_cfg<T, 512, 8, 8>(a, pl, st);
+        return launch_pw_cfg<T, 512, 8, 8>(a, pl, st, fam);
     }
-    if (pl.RB == 128) return pl.CT == 8 ? launch_pw_cfg<T, 128, 8, 4>(a, pl, st) : launch_pw_cfg<T, 128, 4, 4>(a, pl, st);
-    if (pl.RB == 256) return pl.CT == 8 ? launch_pw_cfg<T, 256, 8, 4>(a, pl, st) : launch_pw_cfg<T, 256, 4, 4>(a, pl, st);
+    if (pl.RB == 128) return pl.CT == 8 ? launch_pw_cfg<T, 128, 8, 4>(a, pl, st, fam) : launch_pw_cfg<T, 128, 4, 4>(a, pl, st, fam);
+    if (pl.RB == 256) return pl.CT == 8 ? launch_pw_cfg<T, 256, 8, 4>(a, pl, st, fam) : launch_pw_cfg<T, 256, 4, 4>(a, pl, st, fam);
     YDL_CHECK(pl.CT == 4, "internal: unexpected point-wise plan");
-    return launch_pw_cfg<T, 512, 4, 4>(a, pl, st);
+    return launch_pw_cfg<T, 512, 4, 4>(a, pl, st, fam);
 }
 
 static bool args_pointwise(const IgemmArgs& a) {
@@ -712,7 +704,7 @@ static bool args_pointwise(const IgemmArgs& a) {
 // host side
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int NW = 4, int WP = 4>
-static int launch_igemm(IgemmArgs a, hipStream_t st) {
+static int launch_igemm(IgemmArgs a, hipStream_t st, int fam) {
     a.grid_n = (a.Cst + BN - 1) / BN;
     int mtiles = (a.M + BM - 1) / BM;
     if (a.ncls > 1) {
@@ -723,10 +715,11 @@ static int launch_igemm(IgemmArgs a, hipStream_t st) {
     }
     dim3 grid(mtiles * a.grid_n);
     size_t smem = 2 * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, NW, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    YDL_SET_MAX_LDS((igemm_kernel<T, BM, BN, NW, WP>), smem);
+    {
+        static const std::string nm = std::string("igemm_kernel<") + (sizeof(T) == 4 ? "f32" : "bf16") + "," + std::to_string(BM) + "," +
+                                      std::to_string(BN) + "," + std::to_string(NW) + "," + std::to_string(WP) + ">";
+        ydl_note_kernel(fam, nm.c_str());
     }
     igemm_kernel<T, BM, BN, NW, WP><<<grid, NW * 64, smem, st>>>(a);
     YDL_LAUNCH_CHECK();
@@ -755,7 +748,7 @@ static TileCfg pick_cfg(int M, int Cst) {
 }
 
 template <typename T>
-static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = nullptr, int force_bm = 0) {
+static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid_m_out = nullptr, int force_bm = 0) {
     {
         const PwPlan pl = pw_plan(a.M, a.Kc, a.Cout, a.Cst, (int)sizeof(T), args_pointwise(a));
         if (pl.ok && !force_bm) {
@@ -764,7 +757,7 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = 
             q.M = a.M; q.lda = a.lda; q.ldc = a.ldc; q.Cout = a.Cout; q.WN = pl.WN; q.accumulate = a.accumulate;
             q.block_m = pl.block_m; q.stats_ld = a.stats_ld; q.bytesX = a.bytesA; q.ldw_bytes = a.ldb_bytes;
             if (grid_m_out) *grid_m_out = pl.grid_m;
-            return launch_pw<T>(q, pl, st);
+            return launch_pw<T>(q, pl, st, fam);
         }
     }
     TileCfg c = pick_cfg(a.M, a.Cst);
@@ -776,14 +769,14 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int* grid_m_out = 
     if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
     static const int nw8 = getenv("YDL_NW8") ? atoi(getenv("YDL_NW8")) : 1;
     if (c.BM == 128 && c.BN == 128) {
-        if (nw8 == 2) return launch_igemm<T, 128, 128, 4, 2>(a, st);      // 2x2 waves, 64x64 wave tiles (experiment)
-        return nw8 ? launch_igemm<T, 128, 128, 8>(a, st) : launch_igemm<T, 128, 128, 4>(a, st);
+        if (nw8 == 2) return launch_igemm<T, 128, 128, 4, 2>(a, st, fam);      // 2x2 waves, 64x64 wave tiles (experiment)
+        return nw8 ? launch_igemm<T, 128, 128, 8>(a, st, fam) : launch_igemm<T, 128, 128, 4>(a, st, fam);
     }
-    if (c.BM == 128 && c.BN == 64) return launch_igemm<T, 128, 64>(a, st);
-    if (c.BM == 128 && c.BN == 16) return launch_igemm<T, 128, 16>(a, st);
-    if (c.BM == 64 && c.BN == 128) return nw8 ? launch_igemm<T, 64, 128, 8>(a, st) : launch_igemm<T, 64, 128, 4>(a, st);
-    if (c.BM == 64 && c.BN == 64) return launch_igemm<T, 64, 64>(a, st);
-    return launch_igemm<T, 64, 16>(a, st);
+    if (c.BM == 128 && c.BN == 64) return launch_igemm<T, 128, 64>(a, st, fam);
+    if (c.BM == 128 && c.BN == 16) return launch_igemm<T, 128, 16>(a, st, fam);
+    if (c.BM == 64 && c.BN == 128) return nw8 ? launch_igemm<T, 64, 128, 8>(a, st, fam) : launch_igemm<T, 64, 128, 4>(a, st, fam);
+    if (c.BM == 64 && c.BN == 64) return launch_igemm<T, 64, 64>(a, st, fam);
+    return launch_igemm<T, 64, 16>(a, st, fam);
 }
 
 // byte extents of the gathered tensor and of the weight matrix (raw-buffer range checks: must stay below 4 GiB)
@@ -856,7 +849,7 @@ extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, co
         }
     if (int e = set_extents(a, dtype)) return e;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
+    return dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 0) : dispatch_igemm<bf16_t>(a, st, 0);
 }
 
 extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
@@ -930,7 +923,7 @@ extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy,
         for (int i = 0; i < ncls; ++i) a.M += a.cls_M[i];       // tile choice sees the whole launch
         (void)maxM;
         if (int e2 = set_extents(a, dtype)) return e2;
-        return dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
+        return dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 1) : dispatch_igemm<bf16_t>(a, st, 1);
     }
     for (int ci = 0; ci < ncls; ++ci) {
         const Cls& c = cls[ci];
@@ -940,7 +933,7 @@ extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy,
         a.ntaps = c.nt;
         for (int t = 0; t < c.nt; ++t) { a.dh[t] = c.dh[t]; a.dw[t] = c.dw[t]; a.wt[t] = c.wt[t]; }
         if (int e2 = set_extents(a, dtype)) return e2;
-        int e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st) : dispatch_igemm<bf16_t>(a, st);
+        int e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 1) : dispatch_igemm<bf16_t>(a, st, 1);
         if (e) return e;
     }
     return 0;
@@ -964,6 +957,7 @@ struct WgradArgs {
     unsigned bytesX, bytesY;
     int njt, nct;                 // tile counts (1-D grid = njt * nct * splits)
     int ldw;                      // dW row stride (floats)
+    float* slab;                  // deterministic mode: [splits][Cout][ntaps*Kc] partial sums (plain stores), else NULL
 };
 
 __device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
@@ -1129,7 +1123,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int co = ct * TE + wi * SUB + a * 16 + (lane >> 4) * 4 + e;
-                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
+                    if (co < p.Cout) {
+                        if (p.slab) p.slab[((size_t)zt * p.Cout + co) * wrow + j] = acc[a][b][e];
+                        else atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
+                    }
                 }
             }
         }
@@ -1157,6 +1154,7 @@ struct Wgrad2Args {
     unsigned bytesX, bytesY;
     int njt, nct;
     int ldw;                              // dW row stride (floats)
+    float* slab;                          // deterministic mode: [splits][Cout][ntaps*Kc] partial sums, else NULL
 };
 
 template <int TCO>
@@ -1289,133 +1287,178 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wgrad2Args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int co = ct * TCO + wi * 64 + a * 16 + (lane >> 4) * 4 + e;
-                    if (co < p.Cout) atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
+                    if (co < p.Cout) {
+                        if (p.slab) p.slab[((size_t)zt * p.Cout + co) * wrow + j] = acc[a][b][e];
+                        else atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
+                    }
                 }
             }
         }
 }
 
-static int launch_wgrad2(const ydl_conv_geom* g, const void* x, const void* dy, float* dw, hipStream_t st) {
-    Wgrad2Args a{};
-    a.X = (const bf16_t*)x; a.dY = (const bf16_t*)dy; a.dW = dw;
-    a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = round_up(g->Cin, 8);
-    a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
-    a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = g->k * g->k;
-    a.ldw = g->ldw ? g->ldw : a.ntaps * a.Kc;
-    a.M = g->N * g->Ho * g->Wo;
-    unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * 2ull;
-    unsigned long long by = (unsigned long long)a.M * g->ldy * 2ull;
-    // pixel decode by multiply-shift with magic = ceil(2^40 / d), d <= Ho*Wo: exact for every n <= M while M * d < 2^40
-    YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M * ((unsigned long long)g->Ho * g->Wo) < (1ull << 40),
-              "tensor too large for the 32-bit wgrad addressing");
-    a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by;
-    a.magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
-    a.magicHW = ((1ull << 40) + (unsigned long long)g->Ho * g->Wo - 1) / ((unsigned long long)g->Ho * g->Wo);
-    const int TCO = g->Cout > 64 ? 128 : 64;
-    int jtiles = (a.ntaps * a.Kc + 127) / 128;
-    int ctiles = (g->Cout + TCO - 1) / TCO;
-    long tiles = (long)jtiles * ctiles;
-    int stages = (a.M + 63) / 64;
-    // Split-K CTA count.  Every CTA ends with one atomic pass over its 128 x TCO f32 tile, and device-scope f32 atomics
-    // sustain only ~1.3 TB/s chip-wide (measured), so the atomic volume T * tile_bytes is budgeted at ~20-30 % of the
-    // layer's streaming/MFMA time: short 1x1 layers get 256 CTAs, long 3x3 layers up to 2048 (measured optimum per layer
-    // on MI355X: 128->128 k1 @160: 256 CTAs 55 us vs 1024 CTAs 92 us; 128->64 k3 @160: 1024-1536 CTAs).
-    static const long forced = getenv("YDL_WG2_CTAS") ? atol(getenv("YDL_WG2_CTAS")) : 0;
-    long target2 = forced;
-    if (!target2) {
-        const double bytes_in = ((double)g->N * g->Hi * g->Wi * g->Cin + (double)a.M * g->Cout) * 2.0;
-        const double flops = 2.0 * a.M * g->Cout * a.ntaps * a.Kc;
-        const double d0 = bytes_in / 4.5e12 > flops / 450e12 ? bytes_in / 4.5e12 : flops / 450e12;
-        const double share = a.Kc <= 16 ? 0.3 : 0.2;      // measured: the 3-channel stem prefers more, shorter CTAs
-        const double t = share * d0 * 1.3e12 / (128.0 * TCO * 4.0);
-        target2 = (long)(t / 256.0 + 0.5) * 256;
-        if (target2 < 256) target2 = 256;
-        if (target2 > 2048) target2 = 2048;
+// ---- wgrad launch plan: a pure function of (geometry, dtype, debug knobs); the workspace query and the launch share it
+struct WgradPlan { int kind;     // 0: wgrad_kernel<float>, 1: wgrad_kernel<bf16,tr>, 2: wgrad_kernel<bf16,scalar>, 3: wgrad2<64>, 4: wgrad2<128>
+                   int jtiles, ctiles, splits, chunk; };
+
+static int g_wgrad_tr = 1;
+
+static WgradPlan wgrad_plan(const ydl_conv_geom* g, int dtype) {
+    WgradPlan pl{};
+    const int Kc = round_up(g->Cin, 8), ntaps = g->k * g->k;
+    const int M = g->N * g->Ho * g->Wo;
+    // measured on MI355X: the 128-wide pipelined kernel wins on the large-M layers (>= 160x160 at bs 16), the small
+    // 64x64-tile kernel (8 CTAs/CU) wins where M is small and the grid of big tiles would be latency-bound
+    static const int wg2_min_m = getenv("YDL_WG2_MINM") ? atoi(getenv("YDL_WG2_MINM")) : 200000;
+    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && M >= wg2_min_m) {
+        const int TCO = g->Cout > 64 ? 128 : 64;
+        pl.kind = TCO == 128 ? 4 : 3;
+        pl.jtiles = (ntaps * Kc + 127) / 128;
+        pl.ctiles = (g->Cout + TCO - 1) / TCO;
+        const long tiles = (long)pl.jtiles * pl.ctiles;
+        const int stages = (M + 63) / 64;
+        // Split-K CTA count.  Every CTA ends with one atomic pass over its 128 x TCO f32 tile, and device-scope f32 atomics
+        // sustain only ~1.3 TB/s chip-wide (measured), so the atomic volume T * tile_bytes is budgeted at ~20-30 % of the
+        // layer's streaming/MFMA time: short 1x1 layers get 256 CTAs, long 3x3 layers up to 2048 (measured optimum per layer
+        // on MI355X: 128->128 k1 @160: 256 CTAs 55 us vs 1024 CTAs 92 us; 128->64 k3 @160: 1024-1536 CTAs).
+        static const long forced = getenv("YDL_WG2_CTAS") ? atol(getenv("YDL_WG2_CTAS")) : 0;
+        long target2 = forced;
+        if (!target2) {
+            const double bytes_in = ((double)g->N * g->Hi * g->Wi * g->Cin + (double)M * g->Cout) * 2.0;
+            const double flops = 2.0 * M * g->Cout * ntaps * Kc;
+            const double d0 = bytes_in / 4.5e12 > flops / 450e12 ? bytes_in / 4.5e12 : flops / 450e12;
+            const double share = Kc <= 16 ? 0.3 : 0.2;      // measured: the 3-channel stem prefers more, shorter CTAs
+            const double t = share * d0 * 1.3e12 / (128.0 * TCO * 4.0);
+            target2 = (long)(t / 256.0 + 0.5) * 256;
+            if (target2 < 256) target2 = 256;
+            if (target2 > 2048) target2 = 2048;
+        }
+        int splits = (int)((target2 + tiles - 1) / tiles);
+        if (splits > stages / 4) splits = stages / 4;
+        if (splits < 1) splits = 1;
+        if (splits > 1024) splits = 1024;
+        const int per = (stages + splits - 1) / splits;
+        pl.chunk = per * 64;
+        pl.splits = (M + pl.chunk - 1) / pl.chunk;
+        return pl;
     }
-    int splits = (int)((target2 + tiles - 1) / tiles);
+    pl.kind = dtype == YDL_F32 ? 0 : (g_wgrad_tr ? 1 : 2);
+    const int TE = dtype == YDL_F32 ? 32 : 64;
+    pl.jtiles = (ntaps * Kc + TE - 1) / TE;
+    pl.ctiles = (g->Cout + TE - 1) / TE;
+    // split-K over pixels.  Every split adds one f32 atomic pass over the dW tile (chip-wide atomic rate ~1.3 TB/s),
+    // so splits are bounded by an atomic-byte budget as well as by the CTA target (env knobs for tuning runs)
+    const long tiles = (long)pl.jtiles * pl.ctiles;
+    const int stages = (M + WG_BKP - 1) / WG_BKP;
+    // (measured: the short 1x1 layers are atomic-bound earlier: 1024 CTAs beat 2048 there, 3x3 layers are flat 2048-4096)
+    static const long forced_ctas = getenv("YDL_WG_CTAS") ? atol(getenv("YDL_WG_CTAS")) : 0;
+    const long target_ctas = forced_ctas ? forced_ctas : (ntaps == 1 ? 1024 : 2048);
+    static const long atomic_budget = getenv("YDL_WG_ATOMIC_MB") ? atol(getenv("YDL_WG_ATOMIC_MB")) * (1l << 20) : (1l << 40);
+    int splits = (int)((target_ctas + tiles - 1) / tiles);
+    const long dw_bytes = (long)g->Cout * ntaps * Kc * 4;
+    if ((long)splits * dw_bytes > atomic_budget) splits = (int)(atomic_budget / dw_bytes);
     if (splits > stages / 4) splits = stages / 4;
     if (splits < 1) splits = 1;
     if (splits > 1024) splits = 1024;
-    int per = (stages + splits - 1) / splits;
-    a.chunk = per * 64;
-    splits = (a.M + a.chunk - 1) / a.chunk;
-    a.njt = jtiles; a.nct = ctiles;
-    dim3 grid(jtiles * ctiles * splits);
-    size_t smem = 4 * 64 * W2_ROWB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)wgrad2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
-    if (TCO == 128) wgrad2_kernel<128><<<grid, 256, smem, st>>>(a);
-    else wgrad2_kernel<64><<<grid, 256, smem, st>>>(a);
-    YDL_LAUNCH_CHECK();
-    return 0;
+    const int per = (stages + splits - 1) / splits;
+    pl.chunk = per * WG_BKP;
+    pl.splits = (M + pl.chunk - 1) / pl.chunk;
+    return pl;
 }
 
-static int g_wgrad_tr = 1;
+// deterministic split-K: dW[co][j] += slab[0][co][j] + slab[1][co][j] + ... in that fixed order (one thread per element)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, int splits,
+                                                           int Cout, int wrow, int ldw) {
+    const size_t n = (size_t)Cout * wrow;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[(size_t)z * n + i];
+        const size_t co = i / wrow, j = i - co * wrow;
+        dW[co * ldw + j] += s;
+    }
+}
+
 // debug knobs: key 0 = bf16 wgrad path: 1 (default) 128-wide tr-read kernel, 2 64x64 tr-read kernel, 0 64x64 scalar-LDS-read kernel
 //              key 2 = strided dgrad: 1 (default) all output-parity classes in one launch, 0 one launch per class
 //              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
+// Process-wide and test-only: they change launch geometry, so callers that cache ydl_conv_fwd_grid_m/... must drop the cache
+// after a change (yolo_dual_amd._lib.debug_set does).
 extern "C" void ydl_debug_set(int key, int val) {
     if (key == 0) g_wgrad_tr = val;
     if (key == 1) g_pw_enabled = val;
     if (key == 2) g_dgrad_merge = val;
 }
 
-extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream) {
+extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
+    if (g == nullptr || g->Cin <= 0 || g->Cout <= 0 || g->k < 1) return 0;
+    const WgradPlan pl = wgrad_plan(g, dtype);
+    return (int64_t)pl.splits * g->Cout * (int64_t)(g->k * g->k * round_up(g->Cin, 8)) * (int64_t)sizeof(float);
+}
+
+static int conv_wgrad_impl(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, float* slab, void* stream) {
     if (int e = check_geom(g, dtype)) return e;
     YDL_CHECK(aligned16(x) && aligned16(dy) && aligned16(dw), "pointers must be 16-byte aligned");
     const int V = dtype == YDL_F32 ? 4 : 8;
     YDL_CHECK(g->ldy >= round_up(g->Cout, V), "dy pixel stride must cover Cout rounded up to a 16-byte chunk");
-    WgradArgs a{};
-    a.X = x; a.dY = dy; a.dW = dw;
-    a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = round_up(g->Cin, 8);
-    a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
-    a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = g->k * g->k;
-    a.ldw = g->ldw ? g->ldw : a.ntaps * a.Kc;
-    a.M = g->N * g->Ho * g->Wo;
-    {
-        unsigned long long es = (unsigned long long)esize(dtype);
-        unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * es, by = (unsigned long long)a.M * g->ldy * es;
-        // pixel decode by multiply-shift with magic = ceil(2^40 / d), d <= Ho*Wo: exact for every n <= M while M * d < 2^40
-    YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)a.M * ((unsigned long long)g->Ho * g->Wo) < (1ull << 40),
-                  "tensor too large for the 32-bit wgrad addressing");
-        a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by;
-        a.magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
-        a.magicHW = ((1ull << 40) + (unsigned long long)g->Ho * g->Wo - 1) / ((unsigned long long)g->Ho * g->Wo);
-    }
-    const int TE = dtype == YDL_F32 ? 32 : 64;
-    int jtiles = (a.ntaps * a.Kc + TE - 1) / TE;
-    int ctiles = (g->Cout + TE - 1) / TE;
-    // split-K over pixels.  Every split adds one f32 atomic pass over the dW tile (chip-wide atomic rate ~1.3 TB/s),
-    // so splits are bounded by an atomic-byte budget as well as by the CTA target (env knobs for tuning runs)
-    long tiles = (long)jtiles * ctiles;
-    int stages = (a.M + WG_BKP - 1) / WG_BKP;
-    // (measured: the short 1x1 layers are atomic-bound earlier: 1024 CTAs beat 2048 there, 3x3 layers are flat 2048-4096)
-    static const long forced_ctas = getenv("YDL_WG_CTAS") ? atol(getenv("YDL_WG_CTAS")) : 0;
-    const long target_ctas = forced_ctas ? forced_ctas : (a.ntaps == 1 ? 1024 : 2048);
-    static const long atomic_budget = getenv("YDL_WG_ATOMIC_MB") ? atol(getenv("YDL_WG_ATOMIC_MB")) * (1l << 20) : (1l << 40);
-    int splits = (int)((target_ctas + tiles - 1) / tiles);
-    long dw_bytes = (long)g->Cout * a.ntaps * a.Kc * 4;
-    if ((long)splits * dw_bytes > atomic_budget) splits = (int)(atomic_budget / dw_bytes);
-    if (splits > stages / 4) splits = stages / 4;
-    if (splits < 1) splits = 1;
-    if (splits > 1024) splits = 1024;
-    int per = (stages + splits - 1) / splits;
-    a.chunk = per * WG_BKP;
-    splits = (a.M + a.chunk - 1) / a.chunk;
-    a.njt = jtiles; a.nct = ctiles;
-    dim3 grid(jtiles * ctiles * splits);
+    const WgradPlan pl = wgrad_plan(g, dtype);
+    const int Kc = round_up(g->Cin, 8), ntaps = g->k * g->k;
+    const int M = g->N * g->Ho * g->Wo;
+    const unsigned long long es = (unsigned long long)esize(dtype);
+    const unsigned long long bx = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * es, by = (unsigned long long)M * g->ldy * es;
+    // pixel decode by multiply-shift with magic = ceil(2^40 / d), d <= Ho*Wo: exact for every n <= M while M * d < 2^40
+    YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)M * ((unsigned long long)g->Ho * g->Wo) < (1ull << 40),
+              "tensor too large for the 32-bit wgrad addressing");
+    const unsigned long long magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
+    const unsigned long long magicHW = ((1ull << 40) + (unsigned long long)g->Ho * g->Wo - 1) / ((unsigned long long)g->Ho * g->Wo);
+    const int ldw = g->ldw ? g->ldw : ntaps * Kc;
     hipStream_t st = (hipStream_t)stream;
-    // measured on MI355X: the 128-wide pipelined kernel wins on the large-M layers (>= 160x160 at bs 16), the small
-    // 64x64-tile kernel (8 CTAs/CU) wins where M is small and the grid of big tiles would be latency-bound
-    static const int wg2_min_m = getenv("YDL_WG2_MINM") ? atoi(getenv("YDL_WG2_MINM")) : 200000;
-    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && a.M >= wg2_min_m) return launch_wgrad2(g, x, dy, dw, st);
-    if (dtype == YDL_F32) wgrad_kernel<float, false><<<grid, 256, 0, st>>>(a);
-    else if (g_wgrad_tr) wgrad_kernel<bf16_t, true><<<grid, 256, 0, st>>>(a);
-    else wgrad_kernel<bf16_t, false><<<grid, 256, 0, st>>>(a);
-    YDL_LAUNCH_CHECK();
+    dim3 grid(pl.jtiles * pl.ctiles * pl.splits);
+    if (pl.kind >= 3) {
+        Wgrad2Args a{};
+        a.X = (const bf16_t*)x; a.dY = (const bf16_t*)dy; a.dW = dw;
+        a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = Kc;
+        a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
+        a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = ntaps;
+        a.ldw = ldw; a.M = M; a.chunk = pl.chunk;
+        a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by; a.magicW = magicW; a.magicHW = magicHW;
+        a.njt = pl.jtiles; a.nct = pl.ctiles; a.slab = slab;
+        const size_t smem = 4 * 64 * W2_ROWB;
+        YDL_SET_MAX_LDS((wgrad2_kernel<128>), smem);
+        YDL_SET_MAX_LDS((wgrad2_kernel<64>), smem);
+        ydl_note_kernel(2, pl.kind == 4 ? "wgrad2_kernel<128>" : "wgrad2_kernel<64>");
+        if (pl.kind == 4) wgrad2_kernel<128><<<grid, 256, smem, st>>>(a);
+        else wgrad2_kernel<64><<<grid, 256, smem, st>>>(a);
+        YDL_LAUNCH_CHECK();
+    } else {
+        WgradArgs a{};
+        a.X = x; a.dY = dy; a.dW = dw;
+        a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.ldx = g->ldx; a.Kc = Kc;
+        a.Ho = g->Ho; a.Wo = g->Wo; a.ldy = g->ldy; a.Cout = g->Cout;
+        a.k = g->k; a.s = g->s; a.p = g->p; a.ntaps = ntaps;
+        a.ldw = ldw; a.M = M; a.chunk = pl.chunk;
+        a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by; a.magicW = magicW; a.magicHW = magicHW;
+        a.njt = pl.jtiles; a.nct = pl.ctiles; a.slab = slab;
+        if (pl.kind == 0) { ydl_note_kernel(2, "wgrad_kernel<f32>"); wgrad_kernel<float, false><<<grid, 256, 0, st>>>(a); }
+        else if (pl.kind == 1) { ydl_note_kernel(2, "wgrad_kernel<bf16,tr>"); wgrad_kernel<bf16_t, true><<<grid, 256, 0, st>>>(a); }
+        else { ydl_note_kernel(2, "wgrad_kernel<bf16,scalar>"); wgrad_kernel<bf16_t, false><<<grid, 256, 0, st>>>(a); }
+        YDL_LAUNCH_CHECK();
+    }
+    if (slab) {
+        const int wrow = ntaps * Kc;
+        const size_t n = (size_t)g->Cout * wrow;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(slab, dw, pl.splits, g->Cout, wrow, ldw);
+        YDL_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+extern "C" int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream) {
+    return conv_wgrad_impl(g, dtype, x, dy, dw, nullptr, stream);
+}
+
+extern "C" int ydl_conv_wgrad_det(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, float* ws,
+                                  void* stream) {
+    YDL_CHECK(ws != nullptr && aligned16(ws), "deterministic wgrad needs a 16-byte aligned workspace of ydl_conv_wgrad_ws_bytes()");
+    return conv_wgrad_impl(g, dtype, x, dy, dw, ws, stream);
 }

@@ -144,6 +144,17 @@ class YdlModule(nn.Module):
 # ----------------------------------------------------------------------------------------------------------
 # Conv = Conv2d(bias=False) -> BatchNorm2d -> SiLU
 # ----------------------------------------------------------------------------------------------------------
+def _launch_wgrad(tape: Tape, gp, x_ptr, dy_ptr, dw_ptr, st) -> None:
+    """dW += dy^T * im2col(x): f32 atomics (throughput mode) or the deterministic slab form (parity mode / config)"""
+    if config.deterministic(tape.dname):
+        nbytes = L.lib().ydl_conv_wgrad_ws_bytes(gp, tape.dt)
+        ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=tape.device)
+        L.call("ydl_conv_wgrad_det", gp, tape.dt, x_ptr, dy_ptr, dw_ptr, _p(ws), st)
+        tape._keep.append(ws)          # may be consumed on the side stream: lives until the streams are joined
+    else:
+        L.call("ydl_conv_wgrad", gp, tape.dt, x_ptr, dy_ptr, dw_ptr, st)
+
+
 class _BNHolder(nn.BatchNorm2d):
     """Parameter/buffer holder with nn.BatchNorm2d's state_dict layout.  ``num_batches_tracked`` is advanced on the
     host and flushed into the buffer whenever the state is read, so the hot loop launches no extra kernel."""
@@ -278,13 +289,13 @@ class Conv(YdlModule):
         kk = self.k * self.k
         cin_p = round_up(self.c1, 8)
         if cin_p == self.c1 and gk.is_contiguous():
-            L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
+            _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
             if final:
                 config.mark_touched(p)
             return
         assert col0 == 0 and final
         tmp = torch.zeros((self.c2, kk, cin_p), dtype=torch.float32, device=g.device)
-        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(tmp), st)
+        _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(tmp), st)
         if gk.is_contiguous():
             L.call("ydl_wgrad_unpad", _p(tmp), _p(gk), self.c2, kk, self.c1, 1, st)
         else:                                           # exotic grad layout: let torch place it (cold path)
@@ -349,7 +360,7 @@ class _S2DStem:
         g = m._grad_of(p)
         gk = g.permute(0, 2, 3, 1)
         tmp = torch.zeros((self.c2, self.k * self.k, round_up(self.c1, 8)), dtype=torch.float32, device=g.device)
-        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), _p(tmp), st)
+        _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(tmp), st)
         if gk.is_contiguous():
             L.call("ydl_wgrad_unpack_s2d", _p(tmp), _p(gk), m.c2, m.k, m.s, m.c1, 1, st)
         else:                                           # exotic grad layout: let torch place it (cold path)
@@ -460,7 +471,7 @@ class _FusedPair:
     def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True) -> None:
         p1, p2 = self._grads("w")
         gk = p1.grad.permute(0, 2, 3, 1)
-        L.call("ydl_conv_wgrad", gp, tape.dt, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
+        _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
         if final:
             config.mark_touched(p1)
             config.mark_touched(p2)

@@ -347,7 +347,7 @@ class Tape:
         es = w.element_size()
         Cin_p, Cout_p = round_up(Cin, 8), round_up(Cout, 8)
         if virt is None:
-            gkey = (x.N, x.H, x.W, Cin, Cout, k, s, p, x.ld, y.ld, self.dt)
+            gkey = (x.N, x.H, x.W, Cin, Cout, k, s, p, x.ld, y.ld, self.dt, L.debug_epoch())
             gc = getattr(m, "_geom_cache", None)
             if gc is None or gc[0] != gkey:
                 geom = L.ConvGeom(x.N, x.H, x.W, Cin, Ho, Wo, Cout, k, s, p, x.ld, y.ld, 0)
