@@ -100,6 +100,163 @@ __device__ __forceinline__ void row_reduce(float (&v)[NV], int lrow) {
     }
 }
 
+// Epilogue shared by the tiled kernels: optional accumulate, NHWC store (8 B bf16 / 16 B f32 per lane), and the block-local
+// two-pass BN partial statistics.  ``smem`` is reused as scratch: every LDS read/DMA of the main loop must be complete and
+// fenced by a barrier before the call.
+template <typename T, int BM, int BN, int NW, int WP>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[(BN / (NW / WP)) / 16][BM / (16 * WP)],
+                                               unsigned char* smem, int m0, int n0, int mtile, int c_M, int c_Wg, int c_Hg,
+                                               int c_h0, int c_w0) {
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wc = wave % WN, wp = wave / WN;
+    const int lrow = lane & 15;
+    // ---------------- epilogue: store ----------------
+    T* Cg = (T*)p.C;
+    const int cq = (lane >> 4) * 4;
+    // accumulate: fold the previous contents of C into the accumulators first (whole-vector updates in a separate pass:
+    // keeps the store loop and the statistics below free of per-element selects, which cost 100+ VGPRs when fused)
+    if (p.accumulate) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            int m = m0 + wp * (BM / WP) + j * 16 + lrow;
+            if (m < c_M) {
+                int gw = m % c_Wg;
+                int tmp = m / c_Wg;
+                int gh = tmp % c_Hg;
+                int n = tmp / c_Hg;
+                size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
+                const T* src = Cg + pix * p.ldc;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    int co = n0 + wc * BNW + c * 16 + cq;
+                    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (co + 3 < p.Cst) {
+                        if constexpr (sizeof(T) == 4) {
+                            float4 q4 = *(const float4*)(src + co);
+                            o = f32x4{q4.x, q4.y, q4.z, q4.w};
+                        } else {
+                            uint2 q2 = *(const uint2*)(src + co);
+                            o = f32x4{__uint_as_float(q2.x << 16), __uint_as_float(q2.x & 0xffff0000u),
+                                      __uint_as_float(q2.y << 16), __uint_as_float(q2.y & 0xffff0000u)};
+                        }
+                    } else {
+                        float t0 = co < p.Cst ? ET<T>::ld(src + co) : 0.f;
+                        float t1 = co + 1 < p.Cst ? ET<T>::ld(src + co + 1) : 0.f;
+                        float t2 = co + 2 < p.Cst ? ET<T>::ld(src + co + 2) : 0.f;
+                        o = f32x4{t0, t1, t2, 0.f};
+                    }
+                    acc[c][j] += o;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        int m = m0 + wp * (BM / WP) + j * 16 + lrow;
+        if (m < c_M) {
+            int gw = m % c_Wg;
+            int tmp = m / c_Wg;
+            int gh = tmp % c_Hg;
+            int n = tmp / c_Hg;
+            size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
+            T* dst = Cg + pix * p.ldc;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                int co = n0 + wc * BNW + c * 16 + cq;
+                if (co + 3 < p.Cst) {
+                    if constexpr (sizeof(T) == 4) {
+                        *(float4*)(dst + co) = make_float4(acc[c][j][0], acc[c][j][1], acc[c][j][2], acc[c][j][3]);
+                    } else {
+                        uint2 u;
+                        u.x = (uint32_t)f2bf(acc[c][j][0]) | ((uint32_t)f2bf(acc[c][j][1]) << 16);
+                        u.y = (uint32_t)f2bf(acc[c][j][2]) | ((uint32_t)f2bf(acc[c][j][3]) << 16);
+                        *(uint2*)(dst + co) = u;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Cst) ET<T>::st(dst + co + e, acc[c][j][e]);
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue: BN partial statistics (block-local two-pass => Chan-mergeable) ----------
+    // A lane holds NV = 4*CT channel values per pixel; the sum over the 16 pixel-lanes of a row is a transposing
+    // butterfly (each stage halves the values a lane keeps): 30 shuffles for 32 values instead of 128.
+    if (p.stats != nullptr) {
+        constexpr int NV = 4 * CT;
+        float* red = (float*)smem;             // [4][BN]; safe: all LDS reads finished at the last barrier
+        float* smean = red + WP * BN;          // [BN]
+        const int nvalid = min(BM, c_M - m0);
+        const int lgrp = lane >> 4;
+        float v[NV];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) t2 += acc[c][j][e];   // rows beyond M are exact zeros
+                v[c * 4 + e] = t2;
+            }
+        row_reduce<NV>(v, lrow);
+        // after the reduce, slot tt of lane lrow holds value index (tt << 4 | lrow) (NV >= 16) or (lrow & (NV-1))
+        auto chan_of = [&](int idx) { return wc * BNW + (idx >> 2) * 16 + lgrp * 4 + (idx & 3); };
+        if (NV >= 16) {
+#pragma unroll
+            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wp * BN + chan_of((tt << 4) | lrow)] = v[tt];
+        } else if (lrow < NV) {
+            red[wp * BN + chan_of(lrow)] = v[0];
+        }
+        __syncthreads();
+        float tot = 0.f;
+        if (t < BN) {
+            tot = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < WP; ++g2) tot += red[g2 * BN + t];
+            smean[t] = tot / (float)nvalid;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float mu = smean[wc * BNW + c * 16 + cq + e];
+                float t2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {
+                    int m = m0 + wp * (BM / WP) + j * 16 + lrow;
+                    float d = acc[c][j][e] - mu;
+                    t2 += (m < c_M) ? d * d : 0.f;
+                }
+                v[c * 4 + e] = t2;
+            }
+        row_reduce<NV>(v, lrow);
+        __syncthreads();   // everyone has read smean/red before red is overwritten
+        if (NV >= 16) {
+#pragma unroll
+            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wp * BN + chan_of((tt << 4) | lrow)] = v[tt];
+        } else if (lrow < NV) {
+            red[wp * BN + chan_of(lrow)] = v[0];
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < p.Cout) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < WP; ++g2) m2 += red[g2 * BN + t];
+            float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
+            dst[n0 + t] = tot;
+            dst[p.stats_ld + n0 + t] = m2;
+        }
+    }
+}
+
 // BM = pixel tile (64 or 128), BN = output-channel tile (16, 64 or 128), NW = waves per CTA (4 or 8).
 // Waves form a WP(=4, pixels) x WN(=NW/4, channels) grid: a wave owns BM/4 pixels x BN/WN channels.  The 8-wave
 // form halves the accumulators and LDS fragment reads per wave and doubles the waves per SIMD at the same LDS
@@ -293,146 +450,184 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
         }
     }
 
-    // ---------------- epilogue: store ----------------
-    T* Cg = (T*)p.C;
-    const int cq = (lane >> 4) * 4;
-    // accumulate: fold the previous contents of C into the accumulators first (whole-vector updates in a separate pass:
-    // keeps the store loop and the statistics below free of per-element selects, which cost 100+ VGPRs when fused)
-    if (p.accumulate) {
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            int m = m0 + wp * (BM / WP) + j * 16 + lrow;
-            if (m < c_M) {
-                int gw = m % c_Wg;
-                int tmp = m / c_Wg;
-                int gh = tmp % c_Hg;
-                int n = tmp / c_Hg;
-                size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
-                const T* src = Cg + pix * p.ldc;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    int co = n0 + wc * BNW + c * 16 + cq;
-                    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (co + 3 < p.Cst) {
-                        if constexpr (sizeof(T) == 4) {
-                            float4 q4 = *(const float4*)(src + co);
-                            o = f32x4{q4.x, q4.y, q4.z, q4.w};
-                        } else {
-                            uint2 q2 = *(const uint2*)(src + co);
-                            o = f32x4{__uint_as_float(q2.x << 16), __uint_as_float(q2.x & 0xffff0000u),
-                                      __uint_as_float(q2.y << 16), __uint_as_float(q2.y & 0xffff0000u)};
-                        }
-                    } else {
-                        float t0 = co < p.Cst ? ET<T>::ld(src + co) : 0.f;
-                        float t1 = co + 1 < p.Cst ? ET<T>::ld(src + co + 1) : 0.f;
-                        float t2 = co + 2 < p.Cst ? ET<T>::ld(src + co + 2) : 0.f;
-                        o = f32x4{t0, t1, t2, 0.f};
-                    }
-                    acc[c][j] += o;
-                }
-            }
-        }
+    igemm_epilogue<T, BM, BN, NW, WP>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// igemm2: the same implicit GEMM with an ASYNCHRONOUS operand pipeline (bf16 throughput mode).
+// Both tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging VGPRs, no ds_write pass) into a ring
+// of S stages; a K-step waits only for ITS stage with a counted `s_waitcnt vmcnt`, so S-2 later K-steps stay in flight
+// across the single raw `s_barrier` of the step (a `__syncthreads()` would drain them).  One wave-instruction writes
+// 1 KiB = 8 tile rows x 128 B at wave-uniform base + lane*16, which is exactly the row-major image of igemm_kernel; the
+// XOR swizzle of the 16-byte chunks moves to the per-lane SOURCE address (lane at slot qs of row r fetches logical chunk
+// qs ^ ((r>>1)&7)), the fragment reads are unchanged.  Padding taps, tail rows and K-steps beyond the end are
+// out-of-range buffer offsets: the DMA writes zeros.
+// Per K-step and wave:  wait(own DMAs of step k) -> barrier (everyone's landed; everyone finished reading step k-1)
+//                       -> issue DMAs of step k+S-1 into the stage step k-1 used -> fragment reads + MFMAs of step k.
+// ------------------------------------------------------------------------------------------------------
+#define YDL_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int BM, int BN, int NW, int WP, int S>
+__global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
+    using T = bf16_t;
+    constexpr int V = 8, ES = 2;
+    constexpr int RPP = NW * 8;                 // tile rows covered by one DMA pass of the CTA (one wave = 8 rows)
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows one pass covers");
+    constexpr int AR = BM / RPP, BR = BN / RPP;
+    constexpr int L = AR + BR;                  // DMAs per thread per K-step
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    constexpr int STAGE = (BM + BN) * GROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sTapA = (int*)(smem + S * STAGE);
+    int* sTapB = sTapA + MAXTAPS;
+    int* sTapD = sTapB + MAXTAPS;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WN, wp = wave / WN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mtile = tile / p.grid_n;
+    const int ntile = tile - mtile * p.grid_n;
+    int c_ntaps = p.ntaps, c_tap0 = 0, c_Hg = p.Hg, c_Wg = p.Wg, c_M = p.M, c_h0 = p.out_h0, c_w0 = p.out_w0;
+    if (p.ncls > 1) {
+        int c = 0;
+        while (c + 1 < p.ncls && mtile >= p.cls_tile0[c + 1]) ++c;
+        mtile -= p.cls_tile0[c];
+        c_ntaps = p.cls_ntaps[c]; c_tap0 = p.cls_tap0[c]; c_Hg = p.cls_Hg[c]; c_Wg = p.cls_Wg[c]; c_M = p.cls_M[c];
+        c_h0 = p.cls_h0[c]; c_w0 = p.cls_w0[c];
     }
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+    if (t < MAXTAPS) {
+        int da = 0, db = 0, dd = 0;
+        if (t < c_ntaps) {
+            da = ((int)p.dh[c_tap0 + t] * p.Wi + (int)p.dw[c_tap0 + t]) * p.lda * ES;
+            db = (int)p.wt[c_tap0 + t] * p.Kc * ES;
+            dd = ((int)p.dh[c_tap0 + t] & 0xffff) | ((int)p.dw[c_tap0 + t] << 16);
+        }
+        sTapA[t] = da;
+        sTapB[t] = db;
+        sTapD[t] = dd;
+    }
+    // this thread's DMA slot: row r of each pass, 16-byte slot qs; it fetches the logical chunk q = qs ^ swizzle(r)
+    const int r = t >> 3;
+    const int qs = t & 7;
+    const int q = qs ^ ((r >> 1) & 7);
+    unsigned rowoff[AR];
+    int ih0[AR], iw0[AR];
 #pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        int m = m0 + wp * (BM / WP) + j * 16 + lrow;
+    for (int i = 0; i < AR; ++i) {
+        int m = m0 + r + RPP * i;
+        rowoff[i] = 0;
+        ih0[i] = -100000;
+        iw0[i] = 0;
         if (m < c_M) {
             int gw = m % c_Wg;
             int tmp = m / c_Wg;
             int gh = tmp % c_Hg;
             int n = tmp / c_Hg;
-            size_t pix = ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
-            T* dst = Cg + pix * p.ldc;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                int co = n0 + wc * BNW + c * 16 + cq;
-                if (co + 3 < p.Cst) {
-                    if constexpr (sizeof(T) == 4) {
-                        *(float4*)(dst + co) = make_float4(acc[c][j][0], acc[c][j][1], acc[c][j][2], acc[c][j][3]);
-                    } else {
-                        uint2 u;
-                        u.x = (uint32_t)f2bf(acc[c][j][0]) | ((uint32_t)f2bf(acc[c][j][1]) << 16);
-                        u.y = (uint32_t)f2bf(acc[c][j][2]) | ((uint32_t)f2bf(acc[c][j][3]) << 16);
-                        *(uint2*)(dst + co) = u;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < p.Cst) ET<T>::st(dst + co + e, acc[c][j][e]);
-                }
-            }
+            ih0[i] = gh * p.in_mul;
+            iw0[i] = gw * p.in_mul;
+            rowoff[i] = (unsigned)(((n * p.Hi + ih0[i]) * p.Wi + iw0[i]) * p.lda) * (unsigned)ES;
         }
     }
+    unsigned browoff[BR];
+    bool bvalid[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        int co = n0 + r + RPP * i;
+        bvalid[i] = co < p.Cout;
+        browoff[i] = (unsigned)co * p.ldb_bytes;
+    }
+    const int cpt = p.Kc / V;
+    const int nchunks = c_ntaps * cpt;
+    const int nk = (nchunks + 7) >> 3;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
+    __syncthreads();   // tap tables visible (nothing is in flight yet)
 
-    // ---------------- epilogue: BN partial statistics (block-local two-pass => Chan-mergeable) ----------
-    // A lane holds NV = 4*CT channel values per pixel; the sum over the 16 pixel-lanes of a row is a transposing
-    // butterfly (each stage halves the values a lane keeps): 30 shuffles for 32 values instead of 128.
-    if (p.stats != nullptr) {
-        constexpr int NV = 4 * CT;
-        float* red = (float*)smem;             // [4][BN]; safe: all LDS reads finished at the last barrier
-        float* smean = red + WP * BN;          // [BN]
-        const int nvalid = min(BM, c_M - m0);
-        const int lgrp = lane >> 4;
-        float v[NV];
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t2 = 0.f;
-#pragma unroll
-                for (int j = 0; j < PT; ++j) t2 += acc[c][j][e];   // rows beyond M are exact zeros
-                v[c * 4 + e] = t2;
-            }
-        row_reduce<NV>(v, lrow);
-        // after the reduce, slot tt of lane lrow holds value index (tt << 4 | lrow) (NV >= 16) or (lrow & (NV-1))
-        auto chan_of = [&](int idx) { return wc * BNW + (idx >> 2) * 16 + lgrp * 4 + (idx & 3); };
-        if (NV >= 16) {
-#pragma unroll
-            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wp * BN + chan_of((tt << 4) | lrow)] = v[tt];
-        } else if (lrow < NV) {
-            red[wp * BN + chan_of(lrow)] = v[0];
+    int tap_s = q / cpt, cc_s = q - (q / cpt) * cpt, Q_s = q;
+    // issue the L DMAs of the next K-step (strictly in K order) into ring stage ``stg``
+    auto issue = [&](int stg) {
+        const int Q = Q_s;
+        const int tap = tap_s;
+        const int cc = cc_s * (V * ES);
+        Q_s += 8;
+        if (cpt >= 8) {
+            cc_s += 8;
+            if (cc_s >= cpt) { cc_s -= cpt; ++tap_s; }
+        } else {
+            tap_s = Q_s / cpt;
+            cc_s = Q_s - tap_s * cpt;
         }
-        __syncthreads();
-        float tot = 0.f;
-        if (t < BN) {
-            tot = 0.f;
+        const bool tv = Q < nchunks;
+        const int tidx = tv ? tap : 0;
+        const unsigned da = (unsigned)(sTapA[tidx] + cc);
+        const unsigned db = (unsigned)(sTapB[tidx] + cc);
+        const int dd = sTapD[tidx];
+        const int dh = (int)(short)(dd & 0xffff), dw = dd >> 16;
+        unsigned char* const base = smem + stg * STAGE + wave * (8 * GROWB);
 #pragma unroll
-            for (int g2 = 0; g2 < WP; ++g2) tot += red[g2 * BN + t];
-            smean[t] = tot / (float)nvalid;
+        for (int i = 0; i < AR; ++i) {
+            bool ok = tv && (unsigned)(ih0[i] + dh) < (unsigned)p.Hi && (unsigned)(iw0[i] + dw) < (unsigned)p.Wi;
+            unsigned off = ok ? rowoff[i] + da : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(base + i * RPP * GROWB), 16, off, 0, 0, 0);
         }
-        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int i = 0; i < BR; ++i) {
+            unsigned off = (tv && bvalid[i]) ? browoff[i] + db : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(base + BM * GROWB + i * RPP * GROWB), 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[CT][PT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float mu = smean[wc * BNW + c * 16 + cq + e];
-                float t2 = 0.f;
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int j = 0; j < PT; ++j) {
-                    int m = m0 + wp * (BM / WP) + j * 16 + lrow;
-                    float d = acc[c][j][e] - mu;
-                    t2 += (m < c_M) ? d * d : 0.f;
+        for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int u = 0; u < S - 1; ++u) issue(u);      // K-steps beyond nk are all-zero DMAs: the vmcnt arithmetic stays uniform
+
+    const int lrow = lane & 15;
+    const int sw_rd = (lrow >> 1) & 7;
+    const int lk0 = (((lane >> 4)) ^ sw_rd) << 4;
+    const int lk1 = (((lane >> 4) + 4) ^ sw_rd) << 4;
+    const unsigned char* const fa = smem + BM * GROWB + (wc * BNW + lrow) * GROWB;     // weights  (MFMA A operand)
+    const unsigned char* const fb = smem + (wp * (BM / WP) + lrow) * GROWB;             // pixels   (MFMA B operand)
+    for (int kk0 = 0; kk0 < nk; kk0 += S) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int kk = kk0 + u;
+            if (kk < nk) {
+                YDL_VMCNT(L * (S - 2));            // this wave's DMAs of step kk have landed (S-2 younger steps in flight)
+                __builtin_amdgcn_s_barrier();      // ... and everyone's; all waves are done reading step kk-1
+                issue((u + S - 1) % S);            // step kk+S-1 -> the stage step kk-1 occupied
+                const unsigned char* a_base = fa + u * STAGE;
+                const unsigned char* b_base = fb + u * STAGE;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    uint4 af[CT], bfr[PT];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * GROWB + (s ? lk1 : lk0));
+#pragma unroll
+                    for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * GROWB + (s ? lk1 : lk0));
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
                 }
-                v[c * 4 + e] = t2;
             }
-        row_reduce<NV>(v, lrow);
-        __syncthreads();   // everyone has read smean/red before red is overwritten
-        if (NV >= 16) {
-#pragma unroll
-            for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) red[wp * BN + chan_of((tt << 4) | lrow)] = v[tt];
-        } else if (lrow < NV) {
-            red[wp * BN + chan_of(lrow)] = v[0];
-        }
-        __syncthreads();
-        if (t < BN && n0 + t < p.Cout) {
-            float m2 = 0.f;
-#pragma unroll
-            for (int g2 = 0; g2 < WP; ++g2) m2 += red[g2 * BN + t];
-            float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
-            dst[n0 + t] = tot;
-            dst[p.stats_ld + n0 + t] = m2;
         }
     }
+    YDL_VMCNT(0);                      // the trailing all-zero DMAs must land before the epilogue reuses the LDS
+    __syncthreads();
+    igemm_epilogue<T, BM, BN, NW, WP>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -726,9 +921,63 @@ static int launch_igemm(IgemmArgs a, hipStream_t st, int fam) {
     return 0;
 }
 
-struct TileCfg { int BM, BN; };
-static TileCfg pick_cfg(int M, int Cst) {
+struct TileCfg { int BM, BN; int ring; };     // ring != 0: igemm2_kernel (bf16 LDS-DMA ring) instantiation id
+static int g_ring_enabled = 1;
+
+template <int BM, int BN, int NW, int WP, int S>
+static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
+    a.grid_n = (a.Cst + BN - 1) / BN;
+    int mtiles = (a.M + BM - 1) / BM;
+    if (a.ncls > 1) {
+        int acc = 0;
+        for (int c = 0; c < a.ncls; ++c) { a.cls_tile0[c] = acc; acc += (a.cls_M[c] + BM - 1) / BM; }
+        a.cls_tile0[a.ncls] = acc;
+        mtiles = acc;
+    }
+    dim3 grid(mtiles * a.grid_n);
+    const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
+    YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S>), smem);
+    {
+        static const std::string nm = std::string("igemm2_kernel<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
+                                      std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + ">";
+        ydl_note_kernel(fam, nm.c_str());
+    }
+    igemm2_kernel<BM, BN, NW, WP, S><<<grid, NW * 64, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ring instantiations: id -> (BM, BN)
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128};
+static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
+    switch (id) {
+        case 1: return launch_igemm2<256, 128, 8, 4, 3>(a, st, fam);
+        case 2: return launch_igemm2<128, 128, 4, 2, 4>(a, st, fam);
+        case 3: return launch_igemm2<128, 64, 4, 4, 3>(a, st, fam);
+        case 4: return launch_igemm2<256, 64, 8, 8, 3>(a, st, fam);
+        case 5: return launch_igemm2<128, 128, 8, 4, 4>(a, st, fam);
+    }
+    ydl_set_error("internal: unknown ring kernel id");
+    return 1;
+}
+
+// Tile choice: a pure function of (M, Cst, K chunks, dtype) — the stats-workspace queries call it too.
+static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false) {
     TileCfg c;
+    c.ring = 0;
+    if (bf16 && g_ring_enabled && Cst >= 64 && Cst % 8 == 0 && nchunks >= 16) {
+        // bf16 MFMA-bound layers (>= 2 K-steps of 64): asynchronous ring kernel
+        static const int forced = getenv("YDL_RING") ? atoi(getenv("YDL_RING")) : -1;      // tuning: force an instantiation id
+        int id;
+        if (Cst <= 64) id = (long)((M + 255) / 256) >= 512 ? 4 : 3;
+        else {
+            const long b256 = (long)((M + 255) / 256) * ((Cst + 127) / 128);
+            id = b256 >= 512 ? 1 : 2;
+        }
+        if (forced >= 0) id = forced;
+        if (id > 0) { c.ring = id; c.BM = kRingBM[id]; c.BN = kRingBN[id]; return c; }
+    }
     c.BN = Cst <= 16 ? 16 : (Cst <= 64 ? 64 : 128);
     c.BM = 128;
     // small-M layers: shrink the pixel tile so that the grid still covers the 256 CUs a few times
@@ -760,7 +1009,20 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
             return launch_pw<T>(q, pl, st, fam);
         }
     }
-    TileCfg c = pick_cfg(a.M, a.Cst);
+    // K chunks of the shortest class (multi-class dgrad): the ring kernel wants >= 2 K-steps everywhere
+    int nch = a.ntaps * (a.Kc / (16 / (int)sizeof(T)));
+    if (a.ncls > 1) {
+        nch = 1 << 30;
+        for (int i = 0; i < a.ncls; ++i) nch = min(nch, a.cls_ntaps[i] * (a.Kc / (16 / (int)sizeof(T))));
+    }
+    TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2);
+    if constexpr (sizeof(T) == 2) {
+        if (c.ring && !force_bm) {
+            if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
+            return launch_ring(c.ring, a, st, fam);
+        }
+    }
+    if (c.ring) c = pick_cfg(a.M, a.Cst);
     if (force_bm) c.BM = force_bm;
     static const int env_bm = getenv("YDL_FORCE_BM") ? atoi(getenv("YDL_FORCE_BM")) : 0;     // tuning runs only
     static const int env_bn = getenv("YDL_FORCE_BN") ? atoi(getenv("YDL_FORCE_BN")) : 0;
@@ -813,7 +1075,7 @@ static void fwd_blocks(const ydl_conv_geom* g, int dtype, int* grid_m, int* bloc
     int Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
     const PwPlan pl = pw_plan(M, round_up(g->Cin, 8), g->Cout, Cst, esize(dtype), g->k == 1 && g->s == 1 && g->p == 0);
     if (pl.ok) { *grid_m = pl.grid_m; *block_m = pl.block_m; return; }
-    TileCfg c = pick_cfg(M, Cst);
+    TileCfg c = pick_cfg(M, Cst, g->k * g->k * (round_up(g->Cin, 8) / (16 / esize(dtype))), dtype == YDL_BF16);
     *grid_m = (M + c.BM - 1) / c.BM;
     *block_m = c.BM;
 }
@@ -1380,12 +1642,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // debug knobs: key 0 = bf16 wgrad path: 1 (default) 128-wide tr-read kernel, 2 64x64 tr-read kernel, 0 64x64 scalar-LDS-read kernel
 //              key 2 = strided dgrad: 1 (default) all output-parity classes in one launch, 0 one launch per class
 //              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
+//              key 3 = bf16 LDS-DMA ring kernel (igemm2) for the MFMA-bound layers: 1 (default) on, 0 off (igemm_kernel everywhere)
 // Process-wide and test-only: they change launch geometry, so callers that cache ydl_conv_fwd_grid_m/... must drop the cache
 // after a change (yolo_dual_amd._lib.debug_set does).
 extern "C" void ydl_debug_set(int key, int val) {
     if (key == 0) g_wgrad_tr = val;
     if (key == 1) g_pw_enabled = val;
     if (key == 2) g_dgrad_merge = val;
+    if (key == 3) g_ring_enabled = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
