@@ -16,7 +16,8 @@ LAYERS = [(3, 64, 6, 2, 320), (64, 128, 3, 2, 160), (128, 64, 1, 1, 160), (64, 6
           (128, 256, 3, 2, 80), (256, 128, 1, 1, 80), (128, 128, 3, 1, 80), (256, 256, 1, 1, 80), (256, 512, 3, 2, 40),
           (256, 256, 3, 1, 40), (512, 512, 1, 1, 40), (512, 1024, 3, 2, 20), (512, 512, 3, 1, 20), (2048, 1024, 1, 1, 20),
           (640, 64, 1, 1, 160), (128, 64, 3, 1, 160), (768, 128, 1, 1, 80), (64, 12, 1, 1, 160),
-          (64, 64, 1, 1, 160), (64, 128, 1, 1, 160), (128, 256, 1, 1, 80), (256, 64, 1, 1, 80), (512, 128, 1, 1, 40)]
+          (64, 64, 1, 1, 160), (64, 128, 1, 1, 160), (128, 256, 1, 1, 80), (256, 64, 1, 1, 80), (512, 128, 1, 1, 40),
+          (1024, 1024, 1, 1, 20), (1024, 512, 1, 1, 20), (256, 256, 1, 1, 80)]
 
 
 def main():
@@ -31,9 +32,12 @@ def main():
     ap.add_argument("--pw", type=int, default=1, help="0: tiled kernel for the short-K 1x1 layers")
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many tensor sets (defeats the 256 MB MALL)")
     ap.add_argument("--acc", type=int, default=0, help="dgrad accumulate flag")
+    ap.add_argument("--ring", type=int, default=1, help="0: igemm_kernel instead of the LDS-DMA ring kernel (igemm2)")
+    ap.add_argument("--check", action="store_true", help="compare fwd/dgrad of the ring kernel with igemm_kernel (max abs diff)")
     a = ap.parse_args()
     L.debug_set(0, a.wg)
     L.debug_set(1, a.pw)
+    L.debug_set(3, a.ring)
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")
@@ -69,6 +73,26 @@ def main():
                "dgrad": lambda i: L.call("ydl_conv_dgrad", gp, dt, P(dys[i]), P(wt), P(dxs[i]), a.acc, st),
                "wgrad": lambda i: L.call("ydl_conv_wgrad", gp, dt, P(xs[i]), P(dys[i]), P(dw), st)}
         line = f"[{li:2d}] {Cin:5d}->{Cout:5d} k{k}s{s} @{Ho:4d}"
+        if a.check:
+            outs = []
+            for ring in (1, 0):
+                L.debug_set(3, ring)
+                ws2 = torch.zeros(L.lib().ydl_conv_fwd_stats_ws_bytes(gp, dt) // 4 + 16, device=dev)
+                y2 = torch.zeros_like(ys[0]); dx2 = torch.zeros_like(dxs[0])
+                L.call("ydl_conv_fwd", gp, dt, P(xs[0]), P(w), P(y2), P(ws2), 0, st)
+                kf = L.last_kernel(0)
+                L.call("ydl_conv_dgrad", gp, dt, P(dys[0]), P(wt), P(dx2), 0, st)
+                kd = L.last_kernel(1)
+                gm, bm = L.lib().ydl_conv_fwd_grid_m(gp, dt), L.lib().ydl_conv_fwd_block_m(gp, dt)
+                tot = ws2[:gm * 2 * ldy].view(gm, 2, ldy)[:, 0].double().sum(0)      # per-channel sums from the partials
+                torch.cuda.synchronize()
+                outs.append((y2.float(), dx2.float(), tot, kf, kd))
+            L.debug_set(3, a.ring)
+            dyv = float((outs[0][0] - outs[1][0]).abs().max()); dxv = float((outs[0][1] - outs[1][1]).abs().max())
+            ds = float((outs[0][2] - outs[1][2]).abs().max() / outs[1][2].abs().max().clamp_min(1e-9))
+            print(line + f" | check: max|dy| {dyv:.3g} (scale {float(outs[1][0].abs().max()):.3g}) max|ddx| {dxv:.3g} "
+                  f"(scale {float(outs[1][1].abs().max()):.3g}) stats rel {ds:.2g} | {outs[0][3]} / {outs[0][4]} vs {outs[1][3]} / {outs[1][4]}", flush=True)
+            continue
         for name, fn in ops.items():
             if a.what not in ("all", name):
                 continue
@@ -81,7 +105,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
-            line += f" | {name} {ms * 1e3:7.1f}us {flops / ms / 1e9:5.0f}TF {byts / ms / 1e9:5.2f}TB/s"
+            kn = L.last_kernel({"fwd": 0, "dgrad": 1, "wgrad": 2}[name]).replace("_kernel", "")
+            line += f" | {name} {ms * 1e3:7.1f}us {flops / ms / 1e9:5.0f}TF {byts / ms / 1e9:5.2f}TB/s {kn}"
         print(line, flush=True)
 
 

@@ -43,6 +43,10 @@ struct IgemmArgs {
     int cls_tile0[5];          // first pixel tile of each class (prefix sums), [ncls] = total
     int cls_ntaps[4], cls_tap0[4], cls_Hg[4], cls_Wg[4], cls_M[4], cls_h0[4], cls_w0[4];
     int grid_n;                // number of output-channel tiles (the grid is 1-D: grid_m * grid_n)
+    int grid_m;                // number of pixel tiles (all classes)
+    int dbg;                   // timing experiments only (YDL_RING_DBG): 1 no DMA, 2 DMA sources collapsed onto 64 KB, 3 no epilogue
+    int m_fastest;             // igemm2 tile order: 0 = channel tiles of one pixel tile are neighbours (activations shared in L2),
+                               //                    1 = pixel tiles of one channel tile are neighbours (weight slab stays in L2)
     signed char dh[MAXTAPS], dw[MAXTAPS];
     unsigned char wt[MAXTAPS];
 };
@@ -454,24 +458,217 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// igemm2: the same implicit GEMM with an ASYNCHRONOUS operand pipeline (bf16 throughput mode).
-// Both tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging VGPRs, no ds_write pass) into a ring
-// of S stages; a K-step waits only for ITS stage with a counted `s_waitcnt vmcnt`, so S-2 later K-steps stay in flight
-// across the single raw `s_barrier` of the step (a `__syncthreads()` would drain them).  One wave-instruction writes
-// 1 KiB = 8 tile rows x 128 B at wave-uniform base + lane*16, which is exactly the row-major image of igemm_kernel; the
-// XOR swizzle of the 16-byte chunks moves to the per-lane SOURCE address (lane at slot qs of row r fetches logical chunk
-// qs ^ ((r>>1)&7)), the fragment reads are unchanged.  Padding taps, tail rows and K-steps beyond the end are
-// out-of-range buffer offsets: the DMA writes zeros.
-// Per K-step and wave:  wait(own DMAs of step k) -> barrier (everyone's landed; everyone finished reading step k-1)
-//                       -> issue DMAs of step k+S-1 into the stage step k-1 used -> fragment reads + MFMAs of step k.
+// Epilogue of the bf16 ring kernel.
+//  * stores: the accumulator layout gives a lane 4 consecutive channels of one pixel (8 bytes), so a direct store touches a
+//    pixel row in 32-byte pieces from four different instructions.  Here the tile is transposed through the (now free) LDS
+//    ring as bf16 [pixel][channel] with the 16-byte chunks XOR-swizzled by the row, then every lane stores 16 bytes and 8-16
+//    neighbouring lanes cover a whole pixel row: full-line writes, 1/2 the store instructions.
+//  * BN partials in ONE pass: per lane the exact (n, mean, M2) of its PT values, Chan-merged over the 16 pixel lanes with the
+//    transposing butterfly (each stage halves the live values) and over the WP pixel waves through LDS — same [grid_m][2][C]
+//    (sum, M2) contract as igemm_epilogue, one barrier instead of four.
 // ------------------------------------------------------------------------------------------------------
-#define YDL_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int BM, int BN, int NW, int WP>
+__device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)[(BN / (NW / WP)) / 16][BM / (16 * WP)],
+                                                unsigned char* smem, int m0, int n0, int mtile, int c_M, int c_Wg, int c_Hg,
+                                                int c_h0, int c_w0) {
+    using T = bf16_t;
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    constexpr int NT = NW * 64;
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+    constexpr int ORB = BN * 2;                 // bytes per tile row
+    constexpr int RPS = NT / CPR;               // rows per store pass
+    static_assert(BM % RPS == 0, "store passes must tile the rows");
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wc = wave % WN, wp = wave / WN;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    T* Cg = (T*)p.C;
+    auto pixel_of = [&](int m) -> size_t {
+        const int gw = m % c_Wg;
+        const int tmp = m / c_Wg;
+        const int gh = tmp % c_Hg;
+        const int n = tmp / c_Hg;
+        return ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
+    };
+    const bool dense = p.out_mul == 1 && c_h0 == 0 && c_w0 == 0 && c_Wg == p.Wo && c_Hg == p.Ho;
+    if (p.accumulate) {          // fold the previous contents of C into the accumulators (register layout, 8-byte loads)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int m = m0 + wp * (BM / WP) + j * 16 + lrow;
+            if (m < c_M) {
+                const T* src = Cg + (dense ? (size_t)m : pixel_of(m)) * p.ldc;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const int co = n0 + wc * BNW + c * 16 + lgrp * 4;
+                    if (co < p.Cst) {          // Cst % 8 == 0: a 4-channel group is inside or outside
+                        const uint2 q2 = *(const uint2*)(src + co);
+                        acc[c][j] += f32x4{__uint_as_float(q2.x << 16), __uint_as_float(q2.x & 0xffff0000u),
+                                           __uint_as_float(q2.y << 16), __uint_as_float(q2.y & 0xffff0000u)};
+                    }
+                }
+            }
+        }
+    }
+    // ---- transpose through LDS
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int row = wp * (BM / WP) + j * 16 + lrow;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int ch = wc * BNW + c * 16 + lgrp * 4;          // first of 4 channels
+            uint2 u;
+            u.x = (uint32_t)f2bf(acc[c][j][0]) | ((uint32_t)f2bf(acc[c][j][1]) << 16);
+            u.y = (uint32_t)f2bf(acc[c][j][2]) | ((uint32_t)f2bf(acc[c][j][3]) << 16);
+            const int chunk = (ch >> 3) ^ (row & (CPR - 1) & 15);
+            *(uint2*)(smem + row * ORB + (chunk << 4) + ((ch & 4) << 1)) = u;
+        }
+    }
+    __syncthreads();
+    {
+        const int cq = t % CPR, r0 = t / CPR;
+        const int co = n0 + cq * 8;
+#pragma unroll
+        for (int i = 0; i < BM / RPS; ++i) {
+            const int row = r0 + i * RPS;
+            const int m = m0 + row;
+            if (m < c_M && co < p.Cst) {
+                const uint4 v = *(const uint4*)(smem + row * ORB + ((cq ^ (row & (CPR - 1) & 15)) << 4));
+                *(uint4*)(Cg + (dense ? (size_t)m : pixel_of(m)) * p.ldc + co) = v;
+            }
+        }
+    }
+    if (p.stats == nullptr) return;
+    // ---- BN partial statistics, one pass
+    constexpr int NV = 4 * CT;
+    const int nvalid = min(BM, c_M - m0);
+    float cnt = 0.f;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) cnt += (wp * (BM / WP) + j * 16 + lrow) < nvalid ? 1.f : 0.f;
+    float mean[NV], m2[NV];
+    {
+        const float rn = cnt > 0.f ? 1.f / cnt : 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) s1 += acc[c][j][e];          // rows beyond M are exact zeros
+                const float mu = s1 * rn;
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {
+                    const bool ok = (wp * (BM / WP) + j * 16 + lrow) < nvalid;
+                    const float d = acc[c][j][e] - mu;
+                    q += ok ? d * d : 0.f;
+                }
+                mean[c * 4 + e] = mu;
+                m2[c * 4 + e] = q;
+            }
+    }
+    int live = NV;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int mask = 1 << s;
+        const bool hi = (lrow >> s) & 1;
+        const float cnt_o = __shfl_xor(cnt, mask, 64);
+        const float tot = cnt + cnt_o;
+        const float rt = tot > 0.f ? 1.f / tot : 0.f;
+        const float fo = cnt_o * rt, fx = cnt * cnt_o * rt;
+        if (live > 1) {
+#pragma unroll
+            for (int k = 0; k < NV / 2; ++k)
+                if (k < live / 2) {
+                    const float km = hi ? mean[2 * k + 1] : mean[2 * k], sm = hi ? mean[2 * k] : mean[2 * k + 1];
+                    const float kq = hi ? m2[2 * k + 1] : m2[2 * k], sq = hi ? m2[2 * k] : m2[2 * k + 1];
+                    const float om = __shfl_xor(sm, mask, 64), oq = __shfl_xor(sq, mask, 64);
+                    const float d = om - km;
+                    mean[k] = km + d * fo;
+                    m2[k] = kq + oq + d * d * fx;
+                }
+            live >>= 1;
+        } else {
+            const float om = __shfl_xor(mean[0], mask, 64), oq = __shfl_xor(m2[0], mask, 64);
+            const float d = om - mean[0];
+            mean[0] = mean[0] + d * fo;
+            m2[0] = m2[0] + oq + d * d * fx;
+        }
+        cnt = tot;
+    }
+    // slot tt of lane lrow holds value index (tt << 4 | lrow) (NV >= 16) or (lrow & (NV-1)) in slot 0; channel of index idx =
+    // wc*BNW + (idx>>2)*16 + lgrp*4 + (idx&3)
+    __syncthreads();                               // the store pass has read the transposed tile
+    float* sred = (float*)smem;                    // [WP][BN][2] (mean, M2), then [WP] counts
+    float* scnt = sred + WP * BN * 2;
+    if (NV >= 16) {
+#pragma unroll
+        for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) {
+            const int idx = (tt << 4) | lrow;
+            const int ch = wc * BNW + (idx >> 2) * 16 + lgrp * 4 + (idx & 3);
+            sred[(wp * BN + ch) * 2] = mean[tt];
+            sred[(wp * BN + ch) * 2 + 1] = m2[tt];
+        }
+    } else if (lrow < NV) {
+        const int ch = wc * BNW + (lrow >> 2) * 16 + lgrp * 4 + (lrow & 3);
+        sred[(wp * BN + ch) * 2] = mean[0];
+        sred[(wp * BN + ch) * 2 + 1] = m2[0];
+    }
+    if (lane == 0 && wc == 0) scnt[wp] = cnt;
+    __syncthreads();
+    if (t < BN && n0 + t < p.Cout) {
+        float n = 0.f, mu = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WP; ++w) {
+            const float nb = scnt[w];
+            const float mb = sred[(w * BN + t) * 2], qb = sred[(w * BN + t) * 2 + 1];
+            const float tot = n + nb;
+            const float rt = tot > 0.f ? 1.f / tot : 0.f;
+            const float d = mb - mu;
+            mu = mu + d * nb * rt;
+            q2 = q2 + qb + d * d * n * nb * rt;
+            n = tot;
+        }
+        float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
+        dst[n0 + t] = mu * n;
+        dst[p.stats_ld + n0 + t] = q2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// igemm2: the same implicit GEMM with an ASYNCHRONOUS operand pipeline (bf16 throughput mode, Cin a multiple of 64).
+// Both tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging VGPRs, no ds_write pass) into a ring
+// of S stages; a K-step waits only for ITS stage with a counted `s_waitcnt vmcnt`, so S-2 younger K-steps stay in flight
+// across the single `s_barrier` of the step.  One wave-instruction writes 1 KiB = 8 tile rows x 128 B at (wave-uniform
+// M0 base) + lane*16, which is exactly the row-major image of igemm_kernel; the XOR swizzle of the 16-byte chunks moves
+// to the per-lane SOURCE address (the lane at slot qs of row r fetches logical chunk qs ^ ((r>>1)&7)), the fragment reads
+// are unchanged.  Padding taps, tail rows and the K-steps issued beyond the end are out-of-range buffer offsets, for which
+// the DMA writes zeros (tools/lds_dma_probe.hip checks that on the hardware).
+// With Cin % 64 == 0 every 64-deep K-step lies inside ONE tap, so the tap of a step is wave-uniform: per row the loader
+// keeps a bit mask of its valid taps (computed once), a step costs one v_add3 + and/cmp/select per row.
+// The DMAs are issued from inline asm: the compiler's own wait-count insertion treats an LDS-DMA as a pending LDS write
+// and would drain vmcnt to 0 in front of every fragment read.  Per K-step and wave:
+//     s_waitcnt vmcnt(L*(S-2))  own DMAs of step k have landed (S-2 younger steps stay in flight)
+//     s_barrier                 everyone's have; every wave has finished reading step k-1
+//     issue DMAs of step k+S-1  into the stage step k-1 occupied
+//     fragment reads + MFMAs of step k
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma16(const u32x4& rsrc, unsigned lds_addr, unsigned voff) {
+    // M0 = LDS byte address of the wave's 1 KiB destination (wave-uniform); written in the statement that uses it
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
 
 template <int BM, int BN, int NW, int WP, int S>
 __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
     using T = bf16_t;
-    constexpr int V = 8, ES = 2;
+    constexpr int ES = 2;
     constexpr int RPP = NW * 8;                 // tile rows covered by one DMA pass of the CTA (one wave = 8 rows)
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows one pass covers");
     constexpr int AR = BM / RPP, BR = BN / RPP;
@@ -491,8 +688,9 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wc = wave % WN, wp = wave / WN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int mtile = tile / p.grid_n;
-    const int ntile = tile - mtile * p.grid_n;
+    int mtile, ntile;
+    if (p.m_fastest) { ntile = tile / p.grid_m; mtile = tile - ntile * p.grid_m; }
+    else { mtile = tile / p.grid_n; ntile = tile - mtile * p.grid_n; }
     int c_ntaps = p.ntaps, c_tap0 = 0, c_Hg = p.Hg, c_Wg = p.Wg, c_M = p.M, c_h0 = p.out_h0, c_w0 = p.out_w0;
     if (p.ncls > 1) {
         int c = 0;
@@ -514,75 +712,85 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
         sTapB[t] = db;
         sTapD[t] = dd;
     }
+    __syncthreads();   // tap tables visible (no DMA is in flight yet)
+
     // this thread's DMA slot: row r of each pass, 16-byte slot qs; it fetches the logical chunk q = qs ^ swizzle(r)
     const int r = t >> 3;
     const int qs = t & 7;
-    const int q = qs ^ ((r >> 1) & 7);
-    unsigned rowoff[AR];
-    int ih0[AR], iw0[AR];
+    const unsigned q16 = (unsigned)((qs ^ ((r >> 1) & 7)) << 4);
+    unsigned rowoff[AR], vmask[AR];
+    {
+        int ih0[AR], iw0[AR];
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        int m = m0 + r + RPP * i;
-        rowoff[i] = 0;
-        ih0[i] = -100000;
-        iw0[i] = 0;
-        if (m < c_M) {
-            int gw = m % c_Wg;
-            int tmp = m / c_Wg;
-            int gh = tmp % c_Hg;
-            int n = tmp / c_Hg;
-            ih0[i] = gh * p.in_mul;
-            iw0[i] = gw * p.in_mul;
-            rowoff[i] = (unsigned)(((n * p.Hi + ih0[i]) * p.Wi + iw0[i]) * p.lda) * (unsigned)ES;
+        for (int i = 0; i < AR; ++i) {
+            const int m = m0 + r + RPP * i;
+            rowoff[i] = 0;
+            vmask[i] = 0;
+            ih0[i] = -100000;          // tail rows: no tap is valid => zeros
+            iw0[i] = 0;
+            if (m < c_M) {
+                const int gw = m % c_Wg;
+                const int tmp = m / c_Wg;
+                const int gh = tmp % c_Hg;
+                const int n = tmp / c_Hg;
+                ih0[i] = gh * p.in_mul;
+                iw0[i] = gw * p.in_mul;
+                rowoff[i] = (unsigned)(((n * p.Hi + ih0[i]) * p.Wi + iw0[i]) * p.lda) * (unsigned)ES + q16;
+            }
+        }
+        for (int tp = 0; tp < c_ntaps; ++tp) {            // uniform loop, broadcast LDS reads
+            const int dd = sTapD[tp];
+            const int dh = (int)(short)(dd & 0xffff), dw = dd >> 16;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = (unsigned)(ih0[i] + dh) < (unsigned)p.Hi && (unsigned)(iw0[i] + dw) < (unsigned)p.Wi;
+                vmask[i] |= ok ? (1u << tp) : 0u;
+            }
         }
     }
     unsigned browoff[BR];
-    bool bvalid[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        int co = n0 + r + RPP * i;
-        bvalid[i] = co < p.Cout;
-        browoff[i] = (unsigned)co * p.ldb_bytes;
+        const int co = n0 + r + RPP * i;
+        // rows beyond Cout: a poisoned offset stays out of range whatever is added to it
+        browoff[i] = co < p.Cout ? (unsigned)co * p.ldb_bytes + q16 : 0xF0000000u;
     }
-    const int cpt = p.Kc / V;
-    const int nchunks = c_ntaps * cpt;
-    const int nk = (nchunks + 7) >> 3;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
-    __syncthreads();   // tap tables visible (nothing is in flight yet)
+    const int spt = p.Kc >> 6;                  // 64-channel blocks (Kc % 64 == 0)
+    const int nk = c_ntaps * spt;
+    u32x4 rsA, rsB;
+    {
+        const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+        rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
+        rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xffffu, p.bytesB, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_lds = lds0 + (unsigned)wave * (8 * GROWB);
 
-    int tap_s = q / cpt, cc_s = q - (q / cpt) * cpt, Q_s = q;
-    // issue the L DMAs of the next K-step (strictly in K order) into ring stage ``stg``
+    // K order: 64-channel block outer, tap inner.  All taps of one channel block touch the same input lines (the tile's
+    // halo), so they hit in L2 when they follow each other; tap-outer order re-fetched the whole input tile per tap from
+    // beyond L2 (the reuse distance was the whole K loop) and left the kernel bound by the ~6 TB/s of L2-miss traffic.
+    // Position of the NEXT step to issue (uniform); its table entries are prefetched one step ahead (off the issue path).
+    int tap = 0, cb = 0;
+    int nxtA = sTapA[0], nxtB = sTapB[0];
     auto issue = [&](int stg) {
-        const int Q = Q_s;
-        const int tap = tap_s;
-        const int cc = cc_s * (V * ES);
-        Q_s += 8;
-        if (cpt >= 8) {
-            cc_s += 8;
-            if (cc_s >= cpt) { cc_s -= cpt; ++tap_s; }
-        } else {
-            tap_s = Q_s / cpt;
-            cc_s = Q_s - tap_s * cpt;
-        }
-        const bool tv = Q < nchunks;
-        const int tidx = tv ? tap : 0;
-        const unsigned da = (unsigned)(sTapA[tidx] + cc);
-        const unsigned db = (unsigned)(sTapB[tidx] + cc);
-        const int dd = sTapD[tidx];
-        const int dh = (int)(short)(dd & 0xffff), dw = dd >> 16;
-        unsigned char* const base = smem + stg * STAGE + wave * (8 * GROWB);
+        const int da = nxtA, db = nxtB;
+        const bool live = cb < spt;                                // steps beyond the end: every lane out of range
+        const unsigned kb = (unsigned)cb << 7;                      // byte offset of the channel block
+        const unsigned tbit = live ? 1u << tap : 0u;
+        const unsigned kbB = live ? kb : 0xF0000000u;
+        if (++tap == c_ntaps) { tap = 0; ++cb; }
+        nxtA = sTapA[tap];
+        nxtB = sTapB[tap];
+        const unsigned base = wave_lds + (unsigned)stg * STAGE;
+        if (p.dbg == 1) return;
+        const unsigned amask = p.dbg == 2 ? 0xFFFFu : 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            bool ok = tv && (unsigned)(ih0[i] + dh) < (unsigned)p.Hi && (unsigned)(iw0[i] + dw) < (unsigned)p.Wi;
-            unsigned off = ok ? rowoff[i] + da : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(base + i * RPP * GROWB), 16, off, 0, 0, 0);
+            const unsigned off = (vmask[i] & tbit) ? (rowoff[i] + (unsigned)da + kb) & amask : 0xFFFFFFFFu;
+            lds_dma16(rsA, base + i * RPP * GROWB, off);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            unsigned off = (tv && bvalid[i]) ? browoff[i] + db : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(base + BM * GROWB + i * RPP * GROWB), 16, off, 0, 0, 0);
-        }
+        for (int i = 0; i < BR; ++i) lds_dma16(rsB, base + BM * GROWB + i * RPP * GROWB, (browoff[i] + (unsigned)db + kbB) & (p.dbg == 2 ? 0xF000FFFFu : 0xFFFFFFFFu));
     };
 
     f32x4 acc[CT][PT];
@@ -592,7 +800,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
         for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int u = 0; u < S - 1; ++u) issue(u);      // K-steps beyond nk are all-zero DMAs: the vmcnt arithmetic stays uniform
+    for (int u = 0; u < S - 1; ++u) issue(u);      // steps beyond nk are all-zero DMAs: the vmcnt arithmetic stays uniform
 
     const int lrow = lane & 15;
     const int sw_rd = (lrow >> 1) & 7;
@@ -600,34 +808,58 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
     const int lk1 = (((lane >> 4) + 4) ^ sw_rd) << 4;
     const unsigned char* const fa = smem + BM * GROWB + (wc * BNW + lrow) * GROWB;     // weights  (MFMA A operand)
     const unsigned char* const fb = smem + (wp * (BM / WP) + lrow) * GROWB;             // pixels   (MFMA B operand)
+    // Software-pipelined fragment reads: the fragments of half-step h+1 are in flight while the 16*... MFMAs of half-step h
+    // issue (two register sets).  The wait + barrier that opens step k+1 sits between the two MFMA batches of step k:
+    //   read F1 = frags(k, half 1) | MFMA(F0) | lgkmcnt(0), vmcnt, barrier | issue DMAs(k+S) | read F0 = frags(k+1, half 0) | MFMA(F1)
+    // (by then every wave holds all of step k's fragments in registers, so the DMAs of step k+S may overwrite its stage)
+    uint4 af0[CT], bf0[PT], af1[CT], bf1[PT];
+    auto rdfrag = [&](int stg, int half, uint4 (&af)[CT], uint4 (&bfr)[PT]) {
+        const unsigned char* a_base = fa + stg * STAGE + (half ? lk1 : lk0);
+        const unsigned char* b_base = fb + stg * STAGE + (half ? lk1 : lk0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * GROWB);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * GROWB);
+    };
+    auto mma = [&](const uint4 (&af)[CT], const uint4 (&bfr)[PT]) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+    };
+    if (nk > 0) {
+        wait_vm_barrier<L * (S - 2)>();            // step 0 landed everywhere
+        issue(S - 1);
+        rdfrag(0, 0, af0, bf0);
+    }
     for (int kk0 = 0; kk0 < nk; kk0 += S) {
 #pragma unroll
         for (int u = 0; u < S; ++u) {
             const int kk = kk0 + u;
             if (kk < nk) {
-                YDL_VMCNT(L * (S - 2));            // this wave's DMAs of step kk have landed (S-2 younger steps in flight)
-                __builtin_amdgcn_s_barrier();      // ... and everyone's; all waves are done reading step kk-1
-                issue((u + S - 1) % S);            // step kk+S-1 -> the stage step kk-1 occupied
-                const unsigned char* a_base = fa + u * STAGE;
-                const unsigned char* b_base = fb + u * STAGE;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    uint4 af[CT], bfr[PT];
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * GROWB + (s ? lk1 : lk0));
-#pragma unroll
-                    for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * GROWB + (s ? lk1 : lk0));
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-#pragma unroll
-                        for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+                rdfrag(u, 1, af1, bf1);
+                mma(af0, bf0);
+                if (kk + 1 < nk) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave holds all of step kk in registers
+                    wait_vm_barrier<L * (S - 2)>();                         // step kk+1 landed everywhere
+                    issue(u);                                               // step kk+S -> the stage step kk occupied
+                    rdfrag((u + 1) % S, 0, af0, bf0);
                 }
+                mma(af1, bf1);
             }
         }
     }
-    YDL_VMCNT(0);                      // the trailing all-zero DMAs must land before the epilogue reuses the LDS
-    __syncthreads();
-    igemm_epilogue<T, BM, BN, NW, WP>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0);
+    wait_vm_barrier<0>();              // the trailing all-zero DMAs must land before the epilogue reuses the LDS
+    if (p.dbg == 3) {                  // timing experiment: keep the accumulators live, skip stores and statistics
+        float sink = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) sink += acc[c][j][0] + acc[c][j][1] + acc[c][j][2] + acc[c][j][3];
+        if (sink == 123.456f) ((float*)p.C)[0] = sink;
+        return;
+    }
+    igemm2_epilogue<BM, BN, NW, WP>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -935,6 +1167,19 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
         mtiles = acc;
     }
     dim3 grid(mtiles * a.grid_n);
+    a.grid_m = mtiles;
+    {
+        // tile order (speed only): which operand would be re-fetched from beyond L2?  channel-tile-fastest streams the whole
+        // weight matrix once per pixel tile when it does not fit the XCD's L2; pixel-tile-fastest keeps one weight slab in
+        // L2 and re-reads the activations once per channel tile
+        static const int forced = getenv("YDL_RING_MFAST") ? atoi(getenv("YDL_RING_MFAST")) : -1;
+        const double wbytes = (double)a.Cout * a.Ttot * a.Kc * 2.0;
+        const double abytes = (double)a.N * a.Hi * a.Wi * a.lda * 2.0;
+        a.m_fastest = (wbytes > 2.0e6 && (double)mtiles * wbytes > (double)a.grid_n * abytes) ? 1 : 0;
+        if (forced >= 0) a.m_fastest = forced;
+        static const int dbg = getenv("YDL_RING_DBG") ? atoi(getenv("YDL_RING_DBG")) : 0;
+        a.dbg = dbg;
+    }
     const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
     YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S>), smem);
     {
@@ -948,8 +1193,8 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128};
 static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
     switch (id) {
         case 1: return launch_igemm2<256, 128, 8, 4, 3>(a, st, fam);
@@ -957,24 +1202,28 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         case 3: return launch_igemm2<128, 64, 4, 4, 3>(a, st, fam);
         case 4: return launch_igemm2<256, 64, 8, 8, 3>(a, st, fam);
         case 5: return launch_igemm2<128, 128, 8, 4, 4>(a, st, fam);
+        case 6: return launch_igemm2<128, 128, 4, 2, 2>(a, st, fam);      // 64 KB: two CTAs per CU
+        case 7: return launch_igemm2<128, 128, 8, 4, 2>(a, st, fam);
+        case 8: return launch_igemm2<128, 64, 4, 2, 3>(a, st, fam);       // 72 KB: two CTAs per CU, 64x32 wave tiles
+        case 9: return launch_igemm2<64, 128, 4, 2, 3>(a, st, fam);       // 72 KB: two CTAs per CU, 32x64 wave tiles (small M)
+        case 10: return launch_igemm2<64, 128, 4, 2, 4>(a, st, fam);      // 96 KB: one CTA per CU, deeper ring
     }
     ydl_set_error("internal: unknown ring kernel id");
     return 1;
 }
 
 // Tile choice: a pure function of (M, Cst, K chunks, dtype) — the stats-workspace queries call it too.
-static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false) {
+static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int Kc = 0, int taps = 0) {
     TileCfg c;
     c.ring = 0;
-    if (bf16 && g_ring_enabled && Cst >= 64 && Cst % 8 == 0 && nchunks >= 16) {
-        // bf16 MFMA-bound layers (>= 2 K-steps of 64): asynchronous ring kernel
+    if (bf16 && g_ring_enabled && Cst >= 128 && Cst % 8 == 0 && nchunks >= 16 && Kc > 0 && Kc % 64 == 0 && taps <= 29) {
+        // bf16 MFMA-bound layers (>= 2 K-steps of 64, >= 128 output channels): LDS-DMA ring kernel.  Measured on MI355X over the
+        // 3x3 and wide 1x1 layers of BASELINE config 2 (tools/conv_bench.py, forward and dgrad): the 128x128 tile with a 2-stage
+        // ring (64 KB of LDS, two CTAs per CU: one CTA's epilogue and load latency hide behind the other's MFMAs) beats the
+        // deeper one-CTA-per-CU rings on every layer but the smallest grids, which prefer 64-pixel tiles (more CTAs).
         static const int forced = getenv("YDL_RING") ? atoi(getenv("YDL_RING")) : -1;      // tuning: force an instantiation id
-        int id;
-        if (Cst <= 64) id = (long)((M + 255) / 256) >= 512 ? 4 : 3;
-        else {
-            const long b256 = (long)((M + 255) / 256) * ((Cst + 127) / 128);
-            id = b256 >= 512 ? 1 : 2;
-        }
+        const long b128 = (long)((M + 127) / 128) * ((Cst + 127) / 128);
+        int id = b128 < 256 ? 9 : 7;
         if (forced >= 0) id = forced;
         if (id > 0) { c.ring = id; c.BM = kRingBM[id]; c.BN = kRingBN[id]; return c; }
     }
@@ -1015,7 +1264,7 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
         nch = 1 << 30;
         for (int i = 0; i < a.ncls; ++i) nch = min(nch, a.cls_ntaps[i] * (a.Kc / (16 / (int)sizeof(T))));
     }
-    TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2);
+    TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2, a.Kc, a.Ttot);
     if constexpr (sizeof(T) == 2) {
         if (c.ring && !force_bm) {
             if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
@@ -1075,7 +1324,8 @@ static void fwd_blocks(const ydl_conv_geom* g, int dtype, int* grid_m, int* bloc
     int Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
     const PwPlan pl = pw_plan(M, round_up(g->Cin, 8), g->Cout, Cst, esize(dtype), g->k == 1 && g->s == 1 && g->p == 0);
     if (pl.ok) { *grid_m = pl.grid_m; *block_m = pl.block_m; return; }
-    TileCfg c = pick_cfg(M, Cst, g->k * g->k * (round_up(g->Cin, 8) / (16 / esize(dtype))), dtype == YDL_BF16);
+    TileCfg c = pick_cfg(M, Cst, g->k * g->k * (round_up(g->Cin, 8) / (16 / esize(dtype))), dtype == YDL_BF16,
+                         round_up(g->Cin, 8), g->k * g->k);
     *grid_m = (M + c.BM - 1) / c.BM;
     *block_m = c.BM;
 }
