@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-enum { YDL_F32 = 0, YDL_BF16 = 1 };
+enum { YDL_F32 = 0, YDL_BF16 = 1, YDL_F16 = 2 /* DCNv3 op only */ };
 enum { YDL_ACT_NONE = 0, YDL_ACT_SILU = 1, YDL_ACT_RELU = 2 };
 /* residual handling of the fused BN/activation kernels */
 enum { YDL_RES_NONE = 0, YDL_RES_AFTER_ACT = 1 /* C3/C2f: act(bn(y)) + r */, YDL_RES_BEFORE_ACT = 2 /* ResNet: act(bn(y) + r) */ };
@@ -220,7 +220,12 @@ int ydl_confusion_matrix(const float* pred, int64_t sn, int64_t sc, int64_t sh, 
                          const int64_t* target, int N, int C, int H, int W, int ignore_index,
                          int64_t* matrix /* [C][C], accumulated */, void* stream);
 
-/* ---- DCNv3 (models/ops_dcnv3/src/cuda/dcnv3_cuda.h:15-31; argument order kept) ---------------------- */
+/* ---- DCNv3 (models/ops_dcnv3/src/cuda/dcnv3_cuda.h:15-31) -------------------------------------------------------
+ * Forward: the reference's argument order (tensors, kernel/stride/pad/dilation, group, group_channels, offset_scale),
+ * followed by the sizes the reference reads off its tensors.  Backward: the same, except that grad_output sits with the
+ * other tensors (the reference passes it after offset_scale, dcnv3_cuda.h:24-31) and the three gradients are caller-owned
+ * outputs instead of a returned vector.  `im2col_step` has no counterpart (no batch chunking).  dtype also accepts
+ * YDL_F16 here (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69,147). */
 int ydl_dcnv3_fwd(int dtype, const void* input, const void* offset, const void* mask, void* output,
                   int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
                   int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
@@ -231,6 +236,33 @@ int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, const void* 
                   int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
                   int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
                   int N, int H_in, int W_in, int H_out, int W_out, void* stream);
+
+
+/* ---- pieces of the DCNv3 module around the sampling op (models/ops_dcnv3/build/.../modules/dcnv3.py:50-136) ------------
+ * depth-wise k x k convolution, stride 1, 'same' padding (the `dw_conv = Conv(c, c, k, g=c)` branch, :89);
+ * w is the f32 master weight [C][k*k] (= nn.Conv2d(C, C, k, groups=C).weight, shape [C,1,k,k]); k in {1,3,5,7}. */
+int ydl_dwconv_fwd(int dtype, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C,
+                   int k, int p, void* stream);
+int ydl_dwconv_dgrad(int dtype, const void* dy, int lddy, const float* w, void* dx, int lddx, int accumulate, int N, int H, int W,
+                     int C, int k, int p, void* stream);
+/* dw[C][k*k] += sum over pixels; deterministic (per-block partials in ws, fixed-order merge) */
+int64_t ydl_dwconv_wgrad_ws_bytes(int C, int k);
+int ydl_dwconv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int N, int H, int W, int C,
+                     int k, int p, void* stream);
+/* BN partial statistics of any NHWC tensor in the format ydl_bn_finalize consumes: nblocks = ceil(npix / block_m) rows of
+ * (sum, M2) with block_m = ydl_bn_stats_block_m() */
+int ydl_bn_stats_block_m(void);
+int64_t ydl_bn_stats_ws_bytes(int64_t npix, int C);
+int ydl_bn_stats(int dtype, const void* y, int ldy, float* ws, int64_t npix, int C, void* stream);
+/* out[c] (+)= sum over pixels x[p][c]  (bias gradient of the NHWC nn.Linear layers); deterministic */
+int64_t ydl_channel_sum_ws_bytes(int C);
+int ydl_channel_sum(int dtype, const void* x, int ldx, float* out, float* ws, int64_t npix, int C, int accumulate, void* stream);
+/* soft-max over the P = K*K sampling points of each of the G groups (modules/dcnv3.py:122-123); rows of G*P values */
+int ydl_group_softmax_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int64_t npix, int G, int P, void* stream);
+int ydl_group_softmax_bwd(int dtype, const void* y, int ldy, const void* dy, int lddy, void* dx, int lddx, int accumulate,
+                          int64_t npix, int G, int P, void* stream);
+/* dst[p][0:C] (+)= (compute dtype) src[p][0:C]; src f32 (the DCNv3 op returns f32 gradients, dcnv3_cuda.cu:126-133) */
+int ydl_cast_f32(int dtype, const float* src, int lds, void* dst, int ldd, int64_t npix, int C, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -320,7 +320,7 @@ def gen_dcnv3():
     # models/ops_dcnv3/test.py:19-39 shapes: N=2, M=4 groups, H=W=8, K=3, offset_scale=2, pad=1
     N, M, H, K, pad = 2, 4, 8, 3, 1
     P = K * K
-    for D in (1, 16, 30, 32, 64, 71):
+    for D in (1, 16, 30, 32, 64, 71, 1025):          # test.py:257-260
         rs = np.random.RandomState(300 + D)
         inp = torch.from_numpy(rs.rand(N, H, H, M * D).astype(np.float32) * 0.01).requires_grad_(True)
         off = torch.from_numpy(rs.rand(N, H, H, M * P * 2).astype(np.float32) * 10).requires_grad_(True)
@@ -341,6 +341,35 @@ def gen_dcnv3():
     (out * gup).sum().backward()
     save("dcnv3_s2d2", inp=inp, off=off, msk=msk, out=out, gup=gup, ginp=inp.grad, goff=off.grad, gmsk=msk.grad,
          meta=np.array([K, K, 2, 2, 1, 1, 2, 2, M, D]), offset_scale=np.array(1.0))
+
+
+def gen_dcnv3_module():
+    """the DCNv3 *module* and its YOLO wiring, from the reference's own classes (modules/dcnv3.py:27-136 with the module's
+    relative import replaced by a shim whose ``apply`` is the reference's pure-PyTorch core; "common and yolo.py":2-38)"""
+    nsf = load_ref("models/ops_dcnv3/build/lib.linux-x86_64-cpython-38/functions/dcnv3_func.py", [(92, 189)], extra=dict(DCNv3=None))
+    core = nsf["dcnv3_core_pytorch"]
+
+    class _Fn:                      # DCNv3Function.apply(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, G, Gc, scale, im2col_step)
+        @staticmethod
+        def apply(*a):
+            return core(*a[:14])
+    from torch.nn.init import constant_, xavier_uniform_
+    nsm = load_ref("models/ops_dcnv3/build/lib.linux-x86_64-cpython-38/modules/dcnv3.py", [(17, 136)],
+                   extra=dict(DCNv3Function=_Fn, dcnv3_core_pytorch=core, xavier_uniform_=xavier_uniform_, constant_=constant_))
+    DCNv3 = nsm["DCNv3"]
+    nsc = load_ref("models/common.py", [(38, 64)])
+    nsy = load_ref("models/ops_dcnv3/common and yolo.py", [(2, 38)], extra=dict(Conv=nsc["Conv"], DCNv3=DCNv3))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DCNv3(channels=32, kernel_size=3, stride=1, pad=1, group=4)
+        save("dcnmod_c32_g4", meta=np.array([32, 3, 1, 1, 4]), **run_module(m, [rs_tensor(701, (2, 12, 12, 32))], seed=700))
+        m = DCNv3(channels=24, kernel_size=3, stride=1, pad=1, group=1)
+        save("dcnmod_c24_g1", meta=np.array([24, 3, 1, 1, 1]), **run_module(m, [rs_tensor(703, (2, 9, 11, 24))], seed=702))
+        m = nsy["C3_DCNV3"](32, 32, 1)
+        save("c3_dcnv3_n1", meta=np.array([32, 32, 1]), **run_module(m, [rs_tensor(705, (2, 32, 12, 12))], seed=704))
+        m = nsy["C3_DCNV3"](24, 32, 2, False)
+        save("c3_dcnv3_n2_noshortcut", meta=np.array([24, 32, 2]), **run_module(m, [rs_tensor(707, (2, 24, 10, 10))], seed=706))
 
 
 def gen_miou():
@@ -381,6 +410,10 @@ if __name__ == "__main__":
     if "--models-more" in sys.argv:
         gen_models_more()
         sys.exit(0)
+    if "--dcnv3" in sys.argv:
+        gen_dcnv3()
+        gen_dcnv3_module()
+        sys.exit(0)
     ns5 = gen_blocks_v5()
     gen_losses(ns5)
     gen_blocks_common()
@@ -388,6 +421,7 @@ if __name__ == "__main__":
     gen_blocks_v9()
     ns18, ns50 = gen_resnet()
     gen_dcnv3()
+    gen_dcnv3_module()
     gen_miou()
     gen_optim()
     gen_models(ns5, ns18)

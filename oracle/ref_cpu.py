@@ -396,6 +396,62 @@ def dcnv3_core(inp: torch.Tensor, offset: torch.Tensor, mask: torch.Tensor, kh: 
 
 
 # --------------------------------------------------------------------------------------
+# DCNv3 module and its YOLO wiring (modules/dcnv3.py:50-136, "common and yolo.py":2-38)
+# --------------------------------------------------------------------------------------
+def linear_nhwc(sd: SD, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """nn.Linear on the last dimension of an (N, H, W, C) tensor — modules/dcnv3.py:92-100"""
+    return F.linear(x, sd[pre + ".weight"], sd.get(pre + ".bias"))
+
+
+def dwconv_bn_act(sd: SD, pre: str, x: torch.Tensor, train: bool = True) -> torch.Tensor:
+    """``Conv(c, c, k, g=c)`` of modules/dcnv3.py:89 (:27-39): depth-wise conv -> BN -> SiLU, NCHW in/out"""
+    w = sd[pre + ".conv.weight"]
+    k = w.shape[-1]
+    y = F.conv2d(x, w, None, stride=1, padding=k // 2, groups=w.shape[0])
+    if train and (pre + ".bn.num_batches_tracked") in sd:
+        sd[pre + ".bn.num_batches_tracked"] += 1
+    y = F.batch_norm(y, sd[pre + ".bn.running_mean"], sd[pre + ".bn.running_var"], sd[pre + ".bn.weight"], sd[pre + ".bn.bias"],
+                     train, BN_MOMENTUM, BN_EPS)
+    return F.silu(y)
+
+
+def dcnv3_module(sd: SD, pre: str, inp: torch.Tensor, k: int, stride: int, pad: int, group: int, offset_scale: float = 1.0,
+                 train: bool = True) -> torch.Tensor:
+    """DCNv3.forward — modules/dcnv3.py:109-136.  ``inp`` is (N, H, W, C); dilation is forced to 1 (:82)."""
+    N, H, W, C = inp.shape
+    x = linear_nhwc(sd, pre + ".input_proj", inp)
+    x1 = dwconv_bn_act(sd, pre + ".dw_conv", inp.permute(0, 3, 1, 2), train=train).permute(0, 2, 3, 1)
+    offset = linear_nhwc(sd, pre + ".offset", x1)
+    mask = linear_nhwc(sd, pre + ".mask", x1).reshape(N, H, W, group, -1)
+    mask = F.softmax(mask, -1).reshape(N, H, W, -1)
+    y = dcnv3_core(x, offset, mask, k, k, stride, stride, pad, pad, 1, 1, group, C // group, offset_scale)
+    return linear_nhwc(sd, pre + ".output_proj", y)
+
+
+def dcnv3_yolo(sd: SD, pre: str, x: torch.Tensor, k: int = 3, s: int = 1, g: int = 1, train: bool = True) -> torch.Tensor:
+    """DCNV3_YoLo — "common and yolo.py":2-14: Conv(inc, ouc, 1) then DCNv3(ouc, kernel_size=k, stride=s, group=g) (pad stays 1)"""
+    x = conv_bn_act(sd, pre + ".conv", x, train=train)
+    y = dcnv3_module(sd, pre + ".dcnv3", x.permute(0, 2, 3, 1), k, s, 1, g, train=train)
+    return y.permute(0, 3, 1, 2)
+
+
+def bottleneck_dcnv3(sd: SD, pre: str, x: torch.Tensor, add: bool, g: int = 1, train: bool = True) -> torch.Tensor:
+    """"common and yolo.py":16-25"""
+    y = dcnv3_yolo(sd, pre + ".cv2", conv_bn_act(sd, pre + ".cv1", x, train=train), 3, 1, g, train=train)
+    return x + y if add else y
+
+
+def c3_dcnv3(sd: SD, pre: str, x: torch.Tensor, n: int, shortcut: bool = True, g: int = 1, train: bool = True) -> torch.Tensor:
+    """"common and yolo.py":27-38"""
+    p = (pre + ".") if pre else ""
+    a = conv_bn_act(sd, p + "cv1", x, train=train)
+    for i in range(int(n)):
+        a = bottleneck_dcnv3(sd, f"{p}m.{i}", a, shortcut, g, train=train)
+    b = conv_bn_act(sd, p + "cv2", x, train=train)
+    return conv_bn_act(sd, p + "cv3", torch.cat((a, b), 1), train=train)
+
+
+# --------------------------------------------------------------------------------------
 # mIoU evaluator (val_diceloss.py:37-75): confusion matrix, ignore index nc-1, 0/0 -> 0
 # --------------------------------------------------------------------------------------
 def confusion_matrix(pred_cls: torch.Tensor, target: torch.Tensor, nc: int,

@@ -35,3 +35,96 @@ def test_dcnv3_bf16_runs_close():
     ref = g.t("out")
     # reference tolerance for reduced precision: rtol=1e-2, atol=1e-3 (test.py:85)
     assert torch.allclose(out.float().cpu(), ref, rtol=5e-2, atol=1e-3)
+
+
+def test_dcnv3_fp16_matches_f32():
+    """the op also takes fp16 storage like the reference (AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69,147): C ABI call
+    with YDL_F16 against the f32 golden, reference tolerance for reduced precision (test.py:85: rtol 1e-2, atol 1e-3)"""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd.tape import _p, _stream
+    g = Golden("dcnv3_D32")
+    kh, kw, sh, sw, ph, pw, dh, dw, G, D = [int(v) for v in g.flat["meta"]]
+    inp, off, msk = (g.t(k).cuda().half().contiguous() for k in ("inp", "off", "msk"))
+    N, H, W, C = inp.shape
+    out = torch.empty_like(inp)
+    L.call("ydl_dcnv3_fwd", L.YDL_F16, _p(inp), _p(off), _p(msk), _p(out), kh, kw, sh, sw, ph, pw, dh, dw, G, D,
+           ctypes.c_float(float(g.flat["offset_scale"])), N, H, W, H, W, _stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(out.float().cpu(), g.t("out"), rtol=1e-2, atol=1e-3)
+    gin = torch.zeros(inp.shape, dtype=torch.float32, device="cuda")
+    goff = torch.empty(off.shape, dtype=torch.float32, device="cuda")
+    gmsk = torch.empty(msk.shape, dtype=torch.float32, device="cuda")
+    go = torch.ones_like(inp)
+    L.call("ydl_dcnv3_bwd", L.YDL_F16, _p(inp), _p(off), _p(msk), _p(go), _p(gin), _p(goff), _p(gmsk), kh, kw, sh, sw, ph, pw,
+           dh, dw, G, D, ctypes.c_float(float(g.flat["offset_scale"])), N, H, W, H, W, _stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(gin.cpu(), g.t("ginp"), rtol=2e-2, atol=1e-3)
+    assert torch.allclose(gmsk.cpu(), g.t("gmsk"), rtol=2e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("name", names("dcnmod_"))
+def test_dcnv3_module(name, mode):
+    """the DCNv3 module (modules/dcnv3.py:50-136: input_proj / depth-wise Conv+BN+SiLU / offset + mask Linear / softmax over the
+    K*K points / sampling op / output_proj) against the fixture the reference's own class produced"""
+    import yolo_dual_amd as ydl
+    from tests.test_gpu_blocks import _load, _run
+    ydl.set_compute_dtype(mode)
+    try:
+        g = Golden(name)
+        C, k, s, pad, G = [int(v) for v in g.flat["meta"]]
+        m = _load(ydl.DCNv3(channels=C, kernel_size=k, stride=s, pad=pad, group=G), g)
+        if mode == "bf16":
+            # sampling positions come from bf16-rounded offsets: outputs are compared in relative L2
+            from tests.util import l2_err
+            x = g.t("x0").cuda().requires_grad_(True)
+            out = m(x)
+            assert l2_err(out.detach().cpu(), g.t("out")) < 6e-2
+            (out * g.t("gup").cuda()).sum().backward()
+            assert l2_err(x.grad.cpu(), g.t("gx0")) < 0.2
+            return
+        _run(m, g, mode)
+    finally:
+        ydl.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("name", names("c3_dcnv3_"))
+def test_c3_dcnv3(name, mode):
+    """C3_DCNV3 -> Bottleneck_DCNV3 -> DCNV3_YoLo -> DCNv3 ("common and yolo.py":2-38), fixture from the reference's classes"""
+    import yolo_dual_amd as ydl
+    from tests.util import l2_err, rel_err
+    ydl.set_compute_dtype(mode)
+    try:
+        g = Golden(name)
+        c1, c2, n = [int(v) for v in g.flat["meta"]]
+        m = ydl.C3_DCNV3(c1, c2, n, "noshortcut" not in name)
+        m.load_state_dict(g.group("sd"))
+        m = m.cuda().train()
+        x = g.t("x0").cuda().requires_grad_(True)
+        out = m(x)
+        ref = g.t("out")
+        if mode == "bf16":
+            assert l2_err(out.detach().cpu(), ref) < 8e-2
+            (out * g.t("gup").cuda()).sum().backward()
+            assert torch.isfinite(x.grad).all()
+            return
+        assert rel_err(out.detach().cpu(), ref) < 1e-4, rel_err(out.detach().cpu(), ref)
+        (out * g.t("gup").cuda()).sum().backward()
+        assert rel_err(x.grad.cpu(), g.t("gx0")) < 5e-4
+        grads = g.group("grad")
+        gscale = max(float(v.abs().max()) for v in grads.values())
+        named = dict(m.named_parameters())
+        for kk, v in grads.items():
+            got = named[kk].grad.detach().cpu()
+            if float(v.abs().max()) < 1e-4 * gscale:          # mathematically zero gradients (constant in front of conv + BN)
+                assert float(got.abs().max()) < 1e-3 * gscale, kk
+                continue
+            assert rel_err(got, v) < 2e-3, (kk, rel_err(got, v))
+        after = m.state_dict()
+        for kk, v in g.group("sd_after").items():
+            if v.dtype.is_floating_point:
+                assert rel_err(after[kk].cpu(), v) < 1e-4, kk
+    finally:
+        ydl.set_compute_dtype("bf16")

@@ -93,9 +93,16 @@ TILED = [
     # small-M deep layer: 64-pixel / 64-channel tiles
     ("k1_1024_20_f32", "f32", 16, 1024, 1024, 1, 1, 20, 20, ("igemm_kernel<f32,128,64,4", "igemm_kernel<f32,128,64,4", "wgrad_kernel<f32>", "")),
     # bf16: the throughput-mode instantiations of the same tiles
-    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm_kernel<bf16,128,128,8", "igemm_kernel<bf16,128,128,8", "wgrad_kernel<bf16,tr>", "")),
-    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm_kernel<bf16,128,128,8", "wgrad_kernel<bf16,tr>", "")),
-    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm_kernel<bf16,128,128,8", "igemm_kernel<bf16,128,64,4", "wgrad_kernel<bf16,tr>", "")),
+    # (>= 128 output channels and Cin % 64 == 0: the LDS-DMA ring kernel igemm2; otherwise igemm_kernel)
+    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,128,64,4", "wgrad_kernel<bf16,tr>", "")),
+    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
+    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad_kernel<bf16,tr>", "")),
+    ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    # ragged: 150 output channels (two channel tiles, the second one partial), odd image size, pixel tail
+    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad_kernel<bf16,tr>", "")),
 ]
 
 

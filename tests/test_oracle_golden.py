@@ -339,3 +339,45 @@ def test_model_yolov9seg():
     cfg, mk = _yaml_sd(os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg", "yolov9_seg.yaml"), {})
     _model_check(g, lambda sd, x: R.script_model_forward(sd, cfg, x, (64, 64), family="v9"), mk,
                  dict(class_weights=CW, kind="dice"))
+
+
+@pytest.mark.parametrize("name", names("dcnmod_"))
+def test_dcnv3_module(name):
+    """the DCNv3 module (modules/dcnv3.py:50-136) — fixture from the reference's own class with its pure-PyTorch core"""
+    g = Golden(name)
+    C, k, s, pad, G = [int(v) for v in g.flat["meta"]]
+    sd = _sd(g)
+    wsd, _ = _wrap(sd, "m")
+    x = _x(g)
+    out = R.dcnv3_module(wsd, "m", x, k, s, pad, G)
+    # the restated core gathers explicitly where the reference uses grid_sample: sums re-associate
+    assert rel_err(out, g.t("out")) < 2e-5, g.name
+    (out * g.t("gup")).sum().backward()
+    assert rel_err(x.grad, g.t("gx0")) < 5e-5
+    for kk, v in g.group("grad").items():
+        assert rel_err(sd[kk].grad, v) < 1e-4, (g.name, kk, rel_err(sd[kk].grad, v))
+    for kk, v in g.group("sd_after").items():
+        if v.dtype.is_floating_point:
+            assert rel_err(sd[kk].detach(), v) < TOL, (g.name, kk)
+
+
+@pytest.mark.parametrize("name", names("c3_dcnv3_"))
+def test_c3_dcnv3(name):
+    """C3_DCNV3 / Bottleneck_DCNV3 / DCNV3_YoLo ("common and yolo.py":2-38)"""
+    g = Golden(name)
+    c1, c2, n = [int(v) for v in g.flat["meta"]]
+    sd = _sd(g)
+    wsd, _ = _wrap(sd, "m")
+    x = _x(g)
+    out = R.c3_dcnv3(wsd, "m", x, n, shortcut="noshortcut" not in name)
+    assert rel_err(out, g.t("out")) < 2e-5, g.name
+    (out * g.t("gup")).sum().backward()
+    assert rel_err(x.grad, g.t("gx0")) < 1e-4
+    grads = g.group("grad")
+    gscale = max(float(v.abs().max()) for v in grads.values())
+    for kk, v in grads.items():
+        if float(v.abs().max()) < 1e-4 * gscale:
+            # mathematically zero (a per-channel constant in front of conv + train-mode BN, e.g. output_proj.bias): rounding noise
+            assert float(sd[kk].grad.abs().max()) < 1e-4 * gscale, (g.name, kk)
+            continue
+        assert rel_err(sd[kk].grad, v) < 2e-4, (g.name, kk, rel_err(sd[kk].grad, v))

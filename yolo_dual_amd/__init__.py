@@ -9,8 +9,8 @@ from .evaluate import ConfusionMatrix
 from .loss import JaccardSegmentationLoss, SegmentationLoss
 from .models import (ResNet18, ResNet18Seg, ResNet50, ResNet50Seg, SegYoloModel, YOLOv5Seg, YOLOv8Seg, YOLOv9Seg,
                      parse_model)
-from .modules import (GAM, C2f, C3, C3k2, BasicBlock, Bottleneck, BottleneckBlock, C3Common, Concat, Conv, MaxPool2d,
-                      SegmentHead, SPPF, Upsample, autopad)
+from .modules import (GAM, C2f, C3, C3k2, C3_DCNV3, BasicBlock, Bottleneck, Bottleneck_DCNV3, BottleneckBlock, C3Common, Concat,
+                      Conv, DCNv3, DCNV3_YoLo, Linear, MaxPool2d, SegmentHead, SPPF, Upsample, autopad)
 from .optim import FlatSGDEMA, smart_optimizer
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YDL_LIB", os.path.join(_HERE, "lib", "libydl_hip.so"))   # YDL_LIB: dev override for A/B builds
 
-YDL_F32, YDL_BF16 = 0, 1
+YDL_F32, YDL_BF16, YDL_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 LOSS_DICE, LOSS_JACCARD = 0, 1
@@ -78,6 +78,18 @@ SIGNATURES = {
     "ydl_dcnv3_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp]),
     "ydl_dcnv3_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f,
                            _i, _i, _i, _i, _i, _vp]),
+    "ydl_dwconv_fwd": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ydl_dwconv_dgrad": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ydl_dwconv_wgrad_ws_bytes": (_i64, [_i, _i]),
+    "ydl_dwconv_wgrad": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ydl_bn_stats_block_m": (_i, []),
+    "ydl_bn_stats_ws_bytes": (_i64, [_i64, _i]),
+    "ydl_bn_stats": (_i, [_i, _vp, _i, _vp, _i64, _i, _vp]),
+    "ydl_channel_sum_ws_bytes": (_i64, [_i]),
+    "ydl_channel_sum": (_i, [_i, _vp, _i, _vp, _vp, _i64, _i, _i, _vp]),
+    "ydl_group_softmax_fwd": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
+    "ydl_group_softmax_bwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i64, _i, _i, _vp]),
+    "ydl_cast_f32": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
 }
 
 _lib = None

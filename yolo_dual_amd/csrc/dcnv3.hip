@@ -4,6 +4,26 @@
 // (lanes = group channels, so every NHWC access is a contiguous run), and the grad_offset / grad_mask sums over the
 // channels are wavefront-shuffle butterflies instead of the reference's shared-memory trees.
 #include "common.h"
+#include <stdlib.h>
+
+// fp16 storage (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69,147); only this op takes it
+template <> struct ET<_Float16> {
+    static constexpr int V = 8;
+    __device__ static __forceinline__ float ld(const _Float16* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(_Float16* p, float v) { *p = (_Float16)v; }
+};
+template <> __device__ __forceinline__ void unpack16<_Float16>(const uint4& u, float* f) {
+    const _Float16* h = (const _Float16*)&u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+}
+template <> __device__ __forceinline__ uint4 pack16<_Float16>(const float* f) {
+    uint4 u;
+    _Float16* h = (_Float16*)&u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e];
+    return u;
+}
 
 struct DcnArgs {
     const void* in; const void* off; const void* msk; void* out;        // fwd
@@ -113,6 +133,92 @@ __global__ __launch_bounds__(256) void dcnv3_kernel(const DcnArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Forward, vectorised: a lane owns one 16-byte channel chunk (8 bf16/f16 or 4 f32 channels) of a (pixel, group) item, so
+// a 64-lane load instruction moves 1 KiB of gathered rows instead of 128-256 bytes; the offsets and masks of the CTA's
+// DCN_PIX consecutive pixels are staged once, coalesced, in LDS as f32 (every lane of an item reads the same 3*P values).
+// Same arithmetic as dcnv3_kernel<T, false> (bilinear weights, zero padding, accumulation order over the K*K points).
+// ------------------------------------------------------------------------------------------------------
+#define DCN_PIX 32
+template <typename T>
+__global__ __launch_bounds__(256) void dcnv3_fwd_vec_kernel(const DcnArgs a) {
+    constexpr int V = ET<T>::V;
+    extern __shared__ __attribute__((aligned(16))) float sdcn[];       // [DCN_PIX][G*P*2] offsets, then [DCN_PIX][G*P] masks
+    const int P = a.kh * a.kw;
+    const int C = a.G * a.Gc;
+    const int GP = a.G * P;
+    const long long npix = (long long)a.N * a.Ho * a.Wo;
+    const int cpi = a.Gc / V;                 // chunks per item
+    const int seg = a.seg;                    // lanes per item (power of two >= min(cpi, 64))
+    const int ipw = 64 / seg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / seg, cl = lane % seg;
+    const T* in = (const T*)a.in;
+    float* soff = sdcn;
+    float* smsk = sdcn + (size_t)DCN_PIX * GP * 2;
+    for (long long pb = (long long)blockIdx.x * DCN_PIX; pb < npix; pb += (long long)gridDim.x * DCN_PIX) {
+        const int np = (int)((npix - pb) < DCN_PIX ? (npix - pb) : DCN_PIX);
+        __syncthreads();                      // previous tile's readers are done
+        for (int i = threadIdx.x; i < np * GP * 2; i += 256) soff[i] = ET<T>::ld((const T*)a.off + (size_t)pb * GP * 2 + i);
+        for (int i = threadIdx.x; i < np * GP; i += 256) smsk[i] = ET<T>::ld((const T*)a.msk + (size_t)pb * GP + i);
+        __syncthreads();
+        const int nitems = np * a.G;
+        for (int it0 = wave * ipw; it0 < nitems; it0 += 4 * ipw) {
+            const int item = it0 + sub;
+            const bool live = item < nitems;
+            const int itc = live ? item : 0;
+            const int lp = itc / a.G, g = itc - lp * a.G;
+            const long long pix = pb + lp;
+            const int wo = (int)(pix % a.Wo);
+            const long long t2 = pix / a.Wo;
+            const int ho = (int)(t2 % a.Ho);
+            const int n = (int)(t2 / a.Ho);
+            const int p0w = ((a.dw * (a.kw - 1)) >> 1) - a.pw + wo * a.sw;
+            const int p0h = ((a.dh * (a.kh - 1)) >> 1) - a.ph + ho * a.sh;
+            const float p0w_ = (float)p0w - (float)((a.dw * (a.kw - 1)) >> 1) * a.scale;
+            const float p0h_ = (float)p0h - (float)((a.dh * (a.kh - 1)) >> 1) * a.scale;
+            const float* offp = soff + ((size_t)lp * a.G + g) * P * 2;
+            const float* mskp = smsk + ((size_t)lp * a.G + g) * P;
+            const T* imb = in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
+            for (int q0 = 0; q0 < cpi; q0 += seg) {
+                const int qc = q0 + cl;
+                const bool act = live && qc < cpi;
+                const int c = qc * V;
+                float col[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) col[e] = 0.f;
+                int k = 0;
+                for (int i = 0; i < a.kw; ++i)
+                    for (int j = 0; j < a.kh; ++j, ++k) {
+                        const float ow = offp[2 * k], oh = offp[2 * k + 1], mk = mskp[k];
+                        const float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
+                        const float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
+                        if (act && lh_ > -1.f && lw_ > -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
+                            const int hl = (int)floorf(lh_), wl = (int)floorf(lw_);
+                            const int hh_ = hl + 1, wh_ = wl + 1;
+                            const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
+                            const float hh = 1.f - lh, hw = 1.f - lw;
+                            const bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wh_ <= a.W - 1;
+                            const bool b3 = hh_ <= a.H - 1 && wl >= 0, b4 = hh_ <= a.H - 1 && wh_ <= a.W - 1;
+                            const uint4 z = make_uint4(0, 0, 0, 0);
+                            const uint4 q1 = b1 ? *(const uint4*)(imb + ((size_t)hl * a.W + wl) * C + c) : z;
+                            const uint4 q2 = b2 ? *(const uint4*)(imb + ((size_t)hl * a.W + wh_) * C + c) : z;
+                            const uint4 q3 = b3 ? *(const uint4*)(imb + ((size_t)hh_ * a.W + wl) * C + c) : z;
+                            const uint4 q4 = b4 ? *(const uint4*)(imb + ((size_t)hh_ * a.W + wh_) * C + c) : z;
+                            float v1[V], v2[V], v3[V], v4[V];
+                            unpack16<T>(q1, v1); unpack16<T>(q2, v2); unpack16<T>(q3, v3); unpack16<T>(q4, v4);
+                            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+                            for (int e = 0; e < V; ++e) col[e] += (w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e]) * mk;
+                        }
+                    }
+                if (act) *(uint4*)((T*)a.out + (size_t)pix * C + g * a.Gc + c) = pack16<T>(col);
+            }
+        }
+    }
+}
+
 static int fill_args(DcnArgs& a, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
                      int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
                      int N, int H_in, int W_in, int H_out, int W_out) {
@@ -147,8 +253,28 @@ extern "C" int ydl_dcnv3_fwd(int dtype, const void* input, const void* offset, c
                           group_channels, offset_scale, N, H_in, W_in, H_out, W_out)) return e;
     a.in = input; a.off = offset; a.msk = mask; a.out = output;
     hipStream_t st = (hipStream_t)stream;
+    YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16 || dtype == YDL_F16, "bad dtype");
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int P = kernel_h * kernel_w;
+    const size_t lds = (size_t)DCN_PIX * group * P * 3 * sizeof(float);
+    static const int novec = getenv("YDL_DCN_NOVEC") ? atoi(getenv("YDL_DCN_NOVEC")) : 0;
+    if (!novec && group_channels % V == 0 && lds <= 60 * 1024 && aligned16(input) && aligned16(output)) {
+        // vectorised path: 16-byte chunks, offsets/masks staged in LDS
+        int seg = 1;
+        while (seg < group_channels / V && seg < 64) seg <<= 1;
+        a.seg = seg;
+        const long long npix = (long long)N * H_out * W_out;
+        long long blocks = (npix + DCN_PIX - 1) / DCN_PIX;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (dtype == YDL_F32) dcnv3_fwd_vec_kernel<float><<<(int)blocks, 256, lds, st>>>(a);
+        else if (dtype == YDL_BF16) dcnv3_fwd_vec_kernel<bf16_t><<<(int)blocks, 256, lds, st>>>(a);
+        else dcnv3_fwd_vec_kernel<_Float16><<<(int)blocks, 256, lds, st>>>(a);
+        YDL_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == YDL_F32) dcnv3_kernel<float, false><<<dcn_grid(a), 256, 0, st>>>(a);
-    else dcnv3_kernel<bf16_t, false><<<dcn_grid(a), 256, 0, st>>>(a);
+    else if (dtype == YDL_BF16) dcnv3_kernel<bf16_t, false><<<dcn_grid(a), 256, 0, st>>>(a);
+    else dcnv3_kernel<_Float16, false><<<dcn_grid(a), 256, 0, st>>>(a);
     YDL_LAUNCH_CHECK();
     return 0;
 }
@@ -165,8 +291,10 @@ extern "C" int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, c
     a.in = input; a.off = offset; a.msk = mask; a.gout = grad_output;
     a.gin = grad_input; a.goff = grad_offset; a.gmsk = grad_mask;
     hipStream_t st = (hipStream_t)stream;
+    YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16 || dtype == YDL_F16, "bad dtype");
     if (dtype == YDL_F32) dcnv3_kernel<float, true><<<dcn_grid(a), 256, 0, st>>>(a);
-    else dcnv3_kernel<bf16_t, true><<<dcn_grid(a), 256, 0, st>>>(a);
+    else if (dtype == YDL_BF16) dcnv3_kernel<bf16_t, true><<<dcn_grid(a), 256, 0, st>>>(a);
+    else dcnv3_kernel<_Float16, true><<<dcn_grid(a), 256, 0, st>>>(a);
     YDL_LAUNCH_CHECK();
     return 0;
 }

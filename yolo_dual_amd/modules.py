@@ -24,7 +24,8 @@ from . import config
 from .tape import Tape, Var, round_up, _p, _stream
 
 __all__ = ["autopad", "Conv", "C3", "C3Common", "Bottleneck", "C2f", "C3k2", "GAM", "SPPF", "Concat", "Upsample",
-           "BasicBlock", "BottleneckBlock", "SegmentHead", "run_region"]
+           "BasicBlock", "BottleneckBlock", "SegmentHead", "run_region", "Linear", "DCNv3", "DCNV3_YoLo", "Bottleneck_DCNV3",
+           "C3_DCNV3"]
 
 
 def autopad(k, p=None, d=1):
@@ -84,7 +85,7 @@ def refresh_weights(fn: nn.Module, tape: Tape) -> None:
     """one batched launch re-deriving the compute-layout weights of every stale Conv under ``fn``"""
     convs = getattr(fn, "_ydl_convs", None)
     if convs is None:
-        convs = [m for m in fn.modules() if isinstance(m, Conv)]
+        convs = [m for m in fn.modules() if isinstance(m, Conv) and not m.depthwise]
         fn._ydl_convs = convs
     stale = [m for m in convs if m._wcache.get("key") != m._wkey(tape)]
     if len(stale) < 2:
@@ -205,8 +206,11 @@ class Conv(YdlModule):
             raise TypeError(f"Conv arguments must be int: c1={c1}({type(c1)}), c2={c2}({type(c2)})")
         if g <= 0 or c1 % g != 0:
             raise ValueError(f"groups g={g} must be positive and divide c1={c1}")
-        if g != 1 or d != 1:
-            raise NotImplementedError("the HIP implicit-GEMM path implements groups=1, dilation=1")
+        self.depthwise = g > 1 and g == c1 == c2
+        if d != 1 or (g != 1 and not self.depthwise):
+            raise NotImplementedError("the HIP path implements groups=1 (implicit GEMM) and groups=c1=c2 (depth-wise), dilation=1")
+        if self.depthwise and (s != 1 or k not in (1, 3, 5, 7) or autopad(k, p) != k // 2):
+            raise NotImplementedError("depth-wise Conv: stride 1, k in {1,3,5,7}, 'same' padding (the DCNv3 dw_conv branch)")
         self.c1, self.c2, self.k, self.s = c1, c2, k, s
         self.p = autopad(k, p)
         self.conv = nn.Conv2d(c1, c2, k, s, self.p, groups=g, bias=False)
@@ -303,10 +307,26 @@ class Conv(YdlModule):
         config.mark_touched(p)
 
     # -- forward ----------------------------------------------------------------------------------------
+    # -- depth-wise variant (weight [C,1,k,k]: the KRSC physical layout is [C][k*k]) -------------------------
+    def master_dw(self) -> torch.Tensor:
+        w = self.conv.weight.detach().permute(0, 2, 3, 1)
+        return w if w.is_contiguous() else w.contiguous()
+
+    def grad_dw(self) -> torch.Tensor:
+        g = self._grad_of(self.conv.weight).permute(0, 2, 3, 1)
+        if not g.is_contiguous():
+            raise RuntimeError("depth-wise weight gradient must be KRSC-contiguous")
+        return g
+
     def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None, res: Optional[Var] = None,
              res_mode: int = L.RES_NONE, act_code: Optional[int] = None) -> Var:
         self.mark_step(tape)
         act = self.act_code if act_code is None else act_code
+        if self.depthwise:
+            if res is not None:
+                raise NotImplementedError("depth-wise Conv with a fused residual")
+            y = tape.dwconv_bn_act(x, self, act)
+            return y if out is None else tape.copy(y, out)
         if (x.ext_src is not None and x.real is None and not x.need and config.stem_s2d() and res is None and self.s > 1
                 and self.k % self.s == 0 and self.p % self.s == 0 and self.c1 * self.s * self.s <= 16
                 and x.H % self.s == 0 and x.W % self.s == 0):
@@ -784,3 +804,178 @@ class SegmentHead(YdlModule):
                 f = up._fwd(tape, f)
                 tape.resize(f, H, W, L.RESIZE_BILINEAR_AC, out=sl)
         return self.final_conv[1]._fwd(tape, self.final_conv[0]._fwd(tape, cat))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# DCNv3 module and its YOLO wiring (models/ops_dcnv3/build/.../modules/dcnv3.py:50-136, "common and yolo.py":2-38)
+# ----------------------------------------------------------------------------------------------------------
+class Linear(YdlModule):
+    """``nn.Linear`` over the channel dimension of an NHWC tensor (state_dict: weight [out, in], bias [out]) = a 1x1
+    convolution with bias on the implicit-GEMM kernels; the bias gradient is a deterministic per-channel sum."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+        self._wcache = {}
+
+    def _wkey(self, tape: Tape):
+        return (tape.dname, self.weight.data_ptr(), self.weight._version, config.weight_epoch())
+
+    def compute_weights(self, tape: Tape):
+        key = self._wkey(tape)
+        c = self._wcache
+        if c.get("key") != key or c.get("w") is None or c["w"].dtype != tape.tdt:
+            dev = self.weight.device
+            if c.get("w") is None or c["w"].dtype != tape.tdt or c["w"].device != dev:
+                c["w"] = torch.empty((self.out_features, 1, round_up(self.in_features, 8)), dtype=tape.tdt, device=dev)
+                c["wt"] = torch.empty((self.in_features, 1, round_up(self.out_features, 8)), dtype=tape.tdt, device=dev)
+            master = self.weight.detach()
+            if not master.is_contiguous():
+                master = master.contiguous()
+            L.call("ydl_weight_prep", tape.dt, _p(master), _p(c["w"]), _p(c["wt"]), self.out_features, 1, self.in_features,
+                   _stream())
+            c["key"] = key
+        return c["w"], c["wt"]
+
+    def bias_coeffs(self, device):
+        """(ones, bias) padded to a multiple of 8 channels for ydl_bn_act_fwd (scale = 1, shift = bias)"""
+        cp = round_up(self.out_features, 8)
+        key = (self.bias.data_ptr(), self.bias._version, config.weight_epoch())
+        c = self._wcache
+        if c.get("bkey") != key or c.get("ones") is None or c["ones"].device != device:
+            c["ones"] = torch.ones(cp, dtype=torch.float32, device=device)
+            c["bpad"] = torch.zeros(cp, dtype=torch.float32, device=device)
+        if c.get("bkey") != key:
+            L.call("ydl_copy2d", L.YDL_F32, _p(self.bias.detach()), self.out_features, _p(c["bpad"]), cp, 1, self.out_features, 0,
+                   _stream())
+            c["bkey"] = key
+        return c["ones"], c["bpad"]
+
+    def _grad_of(self, p: nn.Parameter) -> torch.Tensor:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return p.grad
+
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
+        g = self._grad_of(self.weight)
+        cin_p = round_up(self.in_features, 8)
+        if cin_p == self.in_features and g.is_contiguous():
+            _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(g), st)
+        else:
+            tmp = torch.zeros((self.out_features, 1, cin_p), dtype=torch.float32, device=g.device)
+            _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(tmp), st)
+            L.call("ydl_wgrad_unpad", _p(tmp), _p(g), self.out_features, 1, self.in_features, 1, st)
+        config.mark_touched(self.weight)
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        return tape.linear(x, self)
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class DCNv3(YdlModule):
+    """modules/dcnv3.py:50-136.  Input and output are channels-last in the reference ((N, H, W, C)); inside a taped model
+    every activation already is, so the permutes of ``DCNV3_YoLo.forward`` vanish.  Stand-alone calls take the
+    reference's (N, H, W, C) tensor."""
+
+    def __init__(self, channels=64, kernel_size=3, stride=1, pad=1, dilation=1, group=4, offset_scale=1.0,
+                 act_layer="GELU", norm_layer="LN"):
+        super().__init__()
+        if channels % group != 0:
+            raise ValueError(f"channels must be divisible by group, but got {channels} and {group}")
+        if not _is_power_of_2(channels // group):
+            import warnings
+            warnings.warn("You'd better set channels in DCNv3 to make the dimension of each attention head a power of 2 "
+                          "which is more efficient in our CUDA implementation.")
+        self.offset_scale = offset_scale
+        self.channels = channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.dilation = 1                 # the reference ignores its dilation argument (modules/dcnv3.py:82)
+        self.pad = pad
+        self.group = group
+        self.group_channels = channels // group
+        self.dw_conv = Conv(channels, channels, kernel_size, g=channels)
+        self.offset = Linear(channels, group * kernel_size * kernel_size * 2)
+        self.mask = Linear(channels, group * kernel_size * kernel_size)
+        self.input_proj = Linear(channels, channels)
+        self.output_proj = Linear(channels, channels)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        with torch.no_grad():
+            self.offset.weight.zero_(); self.offset.bias.zero_()
+            self.mask.weight.zero_(); self.mask.bias.zero_()
+            nn.init.xavier_uniform_(self.input_proj.weight); self.input_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight); self.output_proj.bias.zero_()
+
+    def forward(self, x, *a, **kw):
+        if isinstance(x, Var):
+            return self._fwd(x.tape, x)
+        # stand-alone: (N, H, W, C) in, (N, H, W, C) out like the reference module
+        return run_region(self, [x.permute(0, 3, 1, 2)]).permute(0, 2, 3, 1)
+
+    def _fwd(self, tape: Tape, inp: Var) -> Var:
+        x = self.input_proj._fwd(tape, inp)
+        x1 = self.dw_conv._fwd(tape, inp)
+        offset = self.offset._fwd(tape, x1)
+        P = self.kernel_size * self.kernel_size
+        mask = tape.group_softmax(self.mask._fwd(tape, x1), self.group, P)
+        y = tape.dcnv3(x, offset, mask, self.kernel_size, self.stride, self.pad, self.dilation, self.group,
+                       self.group_channels, float(self.offset_scale))
+        return self.output_proj._fwd(tape, y)
+
+
+class DCNV3_YoLo(YdlModule):
+    """"common and yolo.py":2-14: Conv(inc, ouc, k=1) -> DCNv3(ouc, kernel_size=k, stride=s, group=g, dilation=d)"""
+
+    def __init__(self, inc, ouc, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        self.conv = Conv(inc, ouc, k=1)
+        self.dcnv3 = DCNv3(ouc, kernel_size=k, stride=s, group=g, dilation=d)
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        return self.dcnv3._fwd(tape, self.conv._fwd(tape, x))
+
+
+class Bottleneck_DCNV3(YdlModule):
+    """"common and yolo.py":16-25"""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = DCNV3_YoLo(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def _fwd(self, tape: Tape, x: Var, out: Optional[Var] = None) -> Var:
+        y = self.cv2._fwd(tape, self.cv1._fwd(tape, x))
+        if self.add:
+            y = tape.add(x, y)
+        return y if out is None else tape.copy(y, out)
+
+
+class C3_DCNV3(YdlModule):
+    """"common and yolo.py":27-38: models/common.py C3 with Bottleneck_DCNV3 inner blocks (no outer residual)"""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck_DCNV3(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
+        self.c_ = c_
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        return _csp_forward(self, tape, x, False)

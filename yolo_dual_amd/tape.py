@@ -574,6 +574,24 @@ class Tape:
             self.bw.append(bw)
         return out
 
+    def add(self, a: Var, b: Var) -> Var:
+        """out = a + b (element-wise, same shape); backward hands d(out) to both"""
+        a, b = self._flat(a) if (a.lazy or a.virtual) else a, self._flat(b) if (b.lazy or b.virtual) else b
+        out = self.new(a.N, a.C, a.H, a.W, f32=(a.dt == L.YDL_F32))
+        st = _stream()
+        L.call("ydl_copy2d", a.dt, _p(a.t), a.ld, _p(out.t), out.ld, a.npix, a.C, 0, st)
+        L.call("ydl_copy2d", b.dt, _p(b.t), b.ld, _p(out.t), out.ld, b.npix, b.C, 1, st)
+        if self.record:
+            def bw():
+                if not out.is_set():
+                    return
+                for v in (a, b):
+                    if v.need:
+                        gv, acc = self.grad_target(v)
+                        L.call("ydl_copy2d", v.dt, _p(self._gbuf(out)), out.ld, _p(gv), v.ld, v.npix, v.C, acc, _stream())
+            self.bw.append(bw)
+        return out
+
     def concat(self, xs: Sequence[Var], align: bool = True) -> Var:
         """Concat along channels with the reference's auto-align (bilinear, align_corners=False, to the first
         input's size) — seg_diceloss_yolov5.py:484-507.
@@ -726,6 +744,154 @@ class Tape:
                     else:
                         gx, _ = self.grad_target(x)
                         L.call("ydl_scale_channels", x.dt, _p(dout), out.ld, _p(gate), _p(gx), x.ld, x.N, HW, x.C, st)
+            self.bw.append(bw)
+        return out
+
+    # ------------------------------------------------------------------ DCNv3 module pieces (NHWC is the tape's native layout)
+    def _flat(self, x: Var) -> Var:
+        x = self.materialize(x)
+        if not x.aligned():
+            x = self.copy(x, self.new(x.N, x.C, x.H, x.W, need=x.need, f32=(x.dt == L.YDL_F32)))
+        return x
+
+    def linear(self, x: Var, lin) -> Var:
+        """nn.Linear on the channel dimension of an NHWC tensor (modules/dcnv3.py:92-100) = 1x1 convolution + bias.
+        ``lin`` holds weight [out, in] (KRSC of a 1x1 conv is the same memory) and bias [out]."""
+        x = self._flat(x)
+        Cin, Cout = lin.in_features, lin.out_features
+        if x.C != Cin:
+            raise RuntimeError(f"Linear input channel mismatch: got {x.C}, weight expects {Cin}")
+        w, wt = lin.compute_weights(self)
+        out = self.new(x.N, Cout, x.H, x.W)
+        geom = L.ConvGeom(x.N, x.H, x.W, Cin, x.H, x.W, Cout, 1, 1, 0, x.ld, out.ld, 0)
+        gp = ctypes.byref(geom)
+        st = _stream()
+        L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(out.t), None, 0, st)
+        if lin.bias is not None:
+            cp = round_up(Cout, 8)
+            ones, bias = lin.bias_coeffs(self.device)
+            L.call("ydl_bn_act_fwd", self.dt, _p(out.t), out.ld, _p(ones), _p(bias), None, 0, L.RES_NONE, L.ACT_NONE,
+                   _p(out.t), out.ld, x.npix, cp, st)
+        if self.record:
+            def bw():
+                if not out.is_set():
+                    return
+                st2 = _stream()
+                dout = self._gbuf(out)
+                dov = Var(self, dout, out.ld, False)
+                if lin.bias is not None:
+                    gb = lin._grad_of(lin.bias)
+                    ws = torch.empty(L.lib().ydl_channel_sum_ws_bytes(Cout) // 4, dtype=torch.float32, device=self.device)
+                    L.call("ydl_channel_sum", self.dt, _p(dout), out.ld, _p(gb), _p(ws), x.npix, Cout, 1, st2)
+                    from . import config as _cfg
+                    _cfg.mark_touched(lin.bias)
+                lin.wgrad(self, gp, x, dov, st2)
+                if x.need:
+                    gx, acc = self.grad_target(x)
+                    L.call("ydl_conv_dgrad", gp, self.dt, _p(dout), _p(wt), _p(gx), acc, st2)
+                self._keep.append(geom)
+            self.bw.append(bw)
+        return out
+
+    def dwconv_bn_act(self, x: Var, m, act: int) -> Var:
+        """depth-wise ``Conv(c, c, k, g=c)`` = conv -> train-mode BN -> SiLU (modules/dcnv3.py:89, :35-39)"""
+        x = self._flat(x)
+        C, k, p = m.c1, m.k, m.p
+        y = self.new(x.N, C, x.H, x.W)
+        out = self.new(x.N, C, x.H, x.W)
+        st = _stream()
+        wm = m.master_dw()                                   # f32 [C][k*k]
+        L.call("ydl_dwconv_fwd", self.dt, _p(x.t), x.ld, _p(wm), _p(y.t), y.ld, x.N, x.H, x.W, C, k, p, st)
+        cf = m.coeffs(self.device)
+        npix = x.npix
+        cp = round_up(C, 8)
+        if self.train:
+            ws = torch.empty(L.lib().ydl_bn_stats_ws_bytes(npix, C) // 4, dtype=torch.float32, device=self.device)
+            bm = L.lib().ydl_bn_stats_block_m()
+            L.call("ydl_bn_stats", self.dt, _p(y.t), y.ld, _p(ws), npix, C, st)
+            L.call("ydl_bn_finalize", _p(ws), (npix + bm - 1) // bm, bm, npix, C, _p(m.bn.weight), _p(m.bn.bias), m.bn.eps,
+                   m.bn.momentum, _p(m.bn.running_mean), _p(m.bn.running_var), _p(cf["mean"]), _p(cf["invstd"]),
+                   _p(cf["scale"]), _p(cf["shift"]), 1, st)
+        else:
+            L.call("ydl_bn_eval_coeffs", C, _p(m.bn.weight), _p(m.bn.bias), _p(m.bn.running_mean), _p(m.bn.running_var),
+                   m.bn.eps, _p(cf["scale"]), _p(cf["shift"]), st)
+        L.call("ydl_bn_act_fwd", self.dt, _p(y.t), y.ld, _p(cf["scale"]), _p(cf["shift"]), None, 0, L.RES_NONE, act,
+               _p(out.t), out.ld, npix, cp, st)
+        if self.record:
+            if not self.train:
+                raise RuntimeError("backward through eval-mode BatchNorm is not supported")
+
+            def bw():
+                if not out.is_set():
+                    return
+                st2 = _stream()
+                dy = self.new(x.N, C, x.H, x.W)
+                gw, accw = m.grad_slot(self, "gamma")
+                gb, _ = m.grad_slot(self, "beta")
+                ws2 = torch.empty(L.lib().ydl_bn_bwd_ws_bytes(npix, cp) // 4, dtype=torch.float32, device=self.device)
+                L.call("ydl_bn_act_bwd", self.dt, _p(y.t), y.ld, _p(self._gbuf(out)), out.ld, _p(out.t), out.ld,
+                       _p(m.bn.weight), _p(cf["mean"]), _p(cf["invstd"]), _p(cf["scale"]), _p(cf["shift"]), L.RES_NONE, act,
+                       _p(dy.t), dy.ld, None, 0, _p(gw), _p(gb), accw, _p(ws2), npix, C, cp, st2)
+                m.touch_bn()
+                gk = m.grad_dw()
+                ws3 = torch.empty(L.lib().ydl_dwconv_wgrad_ws_bytes(C, k) // 4, dtype=torch.float32, device=self.device)
+                L.call("ydl_dwconv_wgrad", self.dt, _p(x.t), x.ld, _p(dy.t), dy.ld, _p(gk), _p(ws3), x.N, x.H, x.W, C, k, p, st2)
+                from . import config as _cfg
+                _cfg.mark_touched(m.conv.weight)
+                if x.need:
+                    gx, acc = self.grad_target(x)
+                    L.call("ydl_dwconv_dgrad", self.dt, _p(dy.t), dy.ld, _p(wm), _p(gx), x.ld, acc, x.N, x.H, x.W, C, k, p, st2)
+            self.bw.append(bw)
+        return out
+
+    def group_softmax(self, x: Var, G: int, P: int) -> Var:
+        """softmax over the P sampling points of each group (modules/dcnv3.py:122-123)"""
+        x = self._flat(x)
+        assert x.C == G * P
+        out = self.new(x.N, x.C, x.H, x.W)
+        L.call("ydl_group_softmax_fwd", self.dt, _p(x.t), x.ld, _p(out.t), out.ld, x.npix, G, P, _stream())
+        if self.record:
+            def bw():
+                if not out.is_set() or not x.need:
+                    return
+                gx, acc = self.grad_target(x)
+                L.call("ydl_group_softmax_bwd", self.dt, _p(out.t), out.ld, _p(self._gbuf(out)), out.ld, _p(gx), x.ld, acc,
+                       x.npix, G, P, _stream())
+            self.bw.append(bw)
+        return out
+
+    def dcnv3(self, x: Var, offset: Var, mask: Var, k: int, s: int, pad: int, dil: int, G: int, Gc: int, scale: float) -> Var:
+        """the deformable sampling op itself (ydl_dcnv3_fwd / _bwd; functions/dcnv3_func.py:19-61).  The op wants dense
+        rows: channel counts that are not multiples of 8 (offset 18*G, mask 9*G) are packed first."""
+        def dense(v: Var) -> torch.Tensor:
+            v = self.materialize(v)
+            if v.ld == v.C and v.parent is None:
+                return v.t.permute(0, 2, 3, 1)
+            buf = torch.empty((v.N, v.H, v.W, v.C), dtype=v.t.dtype, device=self.device)
+            L.call("ydl_copy2d", v.dt, _p(v.t), v.ld, _p(buf), v.C, v.npix, v.C, 0, _stream())
+            return buf
+        xd, od, md = dense(x), dense(offset), dense(mask)
+        N, H, W, C = xd.shape
+        Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // s + 1
+        Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // s + 1
+        out = self.new(N, C, Ho, Wo)
+        assert out.ld == C, "DCNv3: channels must be a multiple of 8"
+        L.call("ydl_dcnv3_fwd", self.dt, _p(xd), _p(od), _p(md), _p(out.t), k, k, s, s, pad, pad, dil, dil, G, Gc,
+               ctypes.c_float(scale), N, H, W, Ho, Wo, _stream())
+        if self.record:
+            def bw():
+                if not out.is_set():
+                    return
+                st2 = _stream()
+                gin = torch.zeros(xd.shape, dtype=torch.float32, device=self.device)
+                goff = torch.empty(od.shape, dtype=torch.float32, device=self.device)
+                gmsk = torch.empty(md.shape, dtype=torch.float32, device=self.device)
+                L.call("ydl_dcnv3_bwd", self.dt, _p(xd), _p(od), _p(md), _p(self._gbuf(out)), _p(gin), _p(goff), _p(gmsk),
+                       k, k, s, s, pad, pad, dil, dil, G, Gc, ctypes.c_float(scale), N, H, W, Ho, Wo, st2)
+                for v, g32 in ((x, gin), (offset, goff), (mask, gmsk)):
+                    if v.need:
+                        gv, acc = self.grad_target(v)
+                        L.call("ydl_cast_f32", v.dt, _p(g32), g32.shape[-1], _p(gv), v.ld, v.npix, v.C, acc, st2)
             self.bw.append(bw)
         return out
 
