@@ -21,38 +21,64 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_IMG = 129.3e9          # algorithmic FLOP / image, fwd+bwd, live graph, convs only
+F_IMG = 129.3e9          # cfg2: algorithmic FLOP / image, fwd+bwd, live graph, convs only
 PEAK_BF16 = 2500.0       # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32 = 157.3         # TFLOP/s f32 MFMA
 PEAK_HBM = 8000.0        # GB/s
 
 
-def load_cfg():
+CW = [1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1]          # unet-lite/yolo5-seg/weight.yaml:3-14
+
+# BASELINE.json configs[1..4] (configs[0] is the CPU plumbing case).  flop_img: conv FLOP per image of one training step
+# (forward + dgrad + wgrad; forward figures from BASELINE.md §2, the stem's input gradient is never needed), None = take the
+# executed conv FLOPs of the instrumented pass.
+WORKLOADS = {
+    "cfg2": dict(model="YOLOv5Seg", yaml="yolov5_seg.yaml", swap={"C3_DCN": "C3"}, loss="dice", cw=True, bs=16, size=640, flop_img=129.3e9,
+                 desc="YOLOv5-backbone (C3+SPPF) + UNet-lite SegmentHead", base="BASELINE configs[1]"),
+    "cfg3": dict(model="ResNet50Seg", loss="dice", cw=False, bs=32, size=640, flop_img=3 * 101.91e9 - 1.93e9,
+                 desc="ResNet50 + multi-scale SegmentHead", base="BASELINE configs[2]"),
+    "cfg4": dict(model="YOLOv8Seg", yaml="yolov8_seg.yaml", swap={"C2f_DCN": "C2f"}, loss="jaccard", cw=True, bs=8, size=1024,
+                 flop_img=3 * 131.47e9 - 3.62e9, desc="YOLOv8 backbone (C2f) + UNet-lite SegmentHead", base="BASELINE configs[3]"),
+    "cfg5": dict(model="YOLOv9Seg", yaml="yolov9_seg.yaml", swap={}, loss="dice", cw=True, bs=16, size=640, flop_img=3 * 89.69e9 - 0.35e9,
+                 desc="YOLOv9 backbone (C3k2 + GAM + SPPF) + UNet-lite SegmentHead (the yaml as shipped: no DCN block)",
+                 base="BASELINE configs[4], reference yaml"),
+    "cfg5dcn": dict(model="YOLOv9Seg", yaml="yolov9_dcnv3_seg.yaml", swap={}, loss="dice", cw=True, bs=16, size=640, flop_img=None,
+                    desc="YOLOv9 backbone with C3_DCNV3 (models/ops_dcnv3) + UNet-lite SegmentHead",
+                    base="BASELINE configs[4], C3-DCN wired through the reference's C3_DCNV3 note"),
+}
+
+
+def load_cfg(name="yolov5_seg.yaml", swap=None):
     import yaml
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "yolo_dual_amd", "cfg", "yolov5_seg.yaml")))
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "yolo_dual_amd", "cfg", name)))
+    swap = {"C3_DCN": "C3"} if swap is None else swap
     for sec in ("backbone", "head"):
         for l in cfg[sec]:
-            if l[2] == "C3_DCN":
-                l[2] = "C3"
+            l[2] = swap.get(l[2], l[2])
     return cfg
 
 
-def cpu_baseline(bs: int, size: int, steps: int):
-    """the CPU oracle's training step (fwd + CE+0.5*Dice + bwd + SGD-nesterov) on all host cores"""
+def cpu_baseline(wl: dict, bs: int, size: int, steps: int):
+    """the CPU oracle's training step (fwd + CE+0.5*Dice|Jaccard + bwd + SGD-nesterov) on all host cores"""
     import torch
     from oracle import ref_cpu as R
     from oracle.fill import fill_state_dict
-    from tests.model_shapes import script_model_state_shapes
-    cfg = load_cfg()
-    shapes = script_model_state_shapes(cfg)
+    from tests.model_shapes import resnet_seg_state_shapes, script_model_state_shapes
+    if wl["model"] == "ResNet50Seg":
+        cfg, shapes = None, resnet_seg_state_shapes("bottleneck", 12)
+    else:
+        cfg = load_cfg(wl["yaml"], wl["swap"])
+        shapes = script_model_state_shapes(cfg)
+    fam = {"YOLOv5Seg": "v5", "YOLOv8Seg": "v8", "YOLOv9Seg": "v9"}.get(wl["model"], "v5")
     sd = {k: (torch.zeros(s) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64))
           for k, s in shapes.items()}
     fill_state_dict(sd, 1, bn_stats=False)
     pnames = [k for k in sd if k.endswith(".weight") or k.endswith(".bias")]
     g = torch.Generator().manual_seed(0)
     x = torch.rand(bs, 3, size, size, generator=g)
-    t = torch.randint(0, 12, (bs, size, size), generator=g)
-    cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+    t_hw = 640 if (cfg is None or size == 1024) else size      # hard-coded 640x640 outputs (segment/train.py:209; T7)
+    t = torch.randint(0, 12, (bs, t_hw, t_hw), generator=g)
+    cw = torch.tensor(CW, dtype=torch.float32) if wl["cw"] else None
     bufs = {}
     times = []
     for st in range(steps + 1):
@@ -60,8 +86,11 @@ def cpu_baseline(bs: int, size: int, steps: int):
         ps = {k: sd[k].detach().clone().requires_grad_(True) for k in pnames}
         run = dict(sd)
         run.update(ps)
-        out = R.script_model_forward(run, cfg, x, (size, size))
-        total, _, _ = R.seg_loss(out, t, cw, "dice")
+        if cfg is None:
+            out = R.resnet_seg_forward(run, x, "bottleneck", out_size=(640, 640))
+        else:
+            out = R.script_model_forward(run, cfg, x, (t_hw, t_hw), family=fam)
+        total, _, _ = R.seg_loss(out, t, cw, wl["loss"])
         total.backward()
         for k in pnames:
             if ps[k].grad is not None:
@@ -81,8 +110,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--bs", type=int, default=16, help="images per GPU")
-    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="cfg2 (default) = BASELINE.json's metric config; cfg3/cfg4/cfg5/cfg5dcn = the other BASELINE configs")
+    ap.add_argument("--bs", type=int, default=0, help="images per GPU (default: the workload's)")
+    ap.add_argument("--size", type=int, default=0, help="input size (default: the workload's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -94,6 +125,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.bs = args.bs or wl["bs"]
+    args.size = args.size or wl["size"]
 
     import torch
     import torch.distributed as dist
@@ -117,17 +151,26 @@ def main():
         ydl.config.set_overlap_wgrad(False)
 
     torch.manual_seed(0)
-    model = ydl.YOLOv5Seg(load_cfg()).to(dev).train()
-    model.img_size = [args.size, args.size]
-    cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)   # weight.yaml:3-14
-    crit = ydl.SegmentationLoss(12, 0.0, cw, "dice", sync=False)
-    # reference hyper-parameters: lr0 0.01, momentum 0.937, weight_decay 5e-4 * bs*accumulate/64 with accumulate=1
+    if wl["model"] == "ResNet50Seg":
+        model = ydl.ResNet50Seg({"nc": 12}).to(dev).train()
+        out_hw = 640                               # segment/train.py:209: the head's output is hard-coded to 640x640
+    else:
+        model = getattr(ydl, wl["model"])(load_cfg(wl["yaml"], wl["swap"])).to(dev).train()
+        # the yaml models resize to img_size (hard-coded 640 in the reference, T7); the benchmark keeps 640 for the 1024 input of
+        # cfg4 like the reference does and follows --size otherwise
+        out_hw = 640 if args.size == 1024 else args.size
+        model.img_size = [out_hw, out_hw]
+    cw = torch.tensor(CW, dtype=torch.float32) if wl["cw"] else None
+    crit = ydl.SegmentationLoss(12, 0.0, cw, wl["loss"], sync=False)
+    # reference hyper-parameters (seg_diceloss_yolov5.py:970-972): lr0 0.01, momentum 0.937, weight_decay 5e-4 * bs*accumulate/64.
+    # The throughput run steps the optimizer every batch (accumulate = 1; the reference would accumulate
+    # round(64/16) = 4 batches at bs 16), which is what the formula is evaluated with here.
     opt = ydl.FlatSGDEMA(model, lr=0.01, momentum=0.937, weight_decay=5e-4 * args.bs * world / 64.0, ema=(rank == 0))
     dp = DataParallel(model, opt) if world > 1 else None
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     imgs = torch.rand(args.bs, 3, args.size, args.size, device=dev, generator=g)
-    tgts = torch.randint(0, 12, (args.bs, args.size, args.size), device=dev, generator=g)
+    tgts = torch.randint(0, 12, (args.bs, out_hw, out_hw), device=dev, generator=g)
 
     def step():
         opt.zero_grad()
@@ -238,17 +281,19 @@ def main():
                 json.dump(rec, fh)
         fam = {}
         for r in rec:
-            f = fam.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "n": 0})
-            f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["n"] += 1
+            f = fam.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "n": 0, "bytes": 0.0})
+            f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["n"] += 1; f["bytes"] += r.get("bytes", 0.0)
         tot_ms = sum(f["ms"] for f in fam.values())
         dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, f = dom
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")
-        if os.path.exists(tpath):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
+        tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic_pmc.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")
+        if os.path.exists(tpath) and args.workload == "cfg2":      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
             try:
                 tj = json.load(open(tpath))
-                ig = [k for k in tj["kernels"] if "igemm_kernel" in k["kernel"] or "pw_kernel" in k["kernel"]]
+                ig = [k for k in tj["kernels"] if "igemm" in k["kernel"] or "pw_kernel" in k["kernel"]]
                 n_l = sum(k["launches_per_step"] for k in ig)
                 traffic = {"unit": "MB per launch (conv fwd+dgrad launches: igemm_kernel + pw_kernel, PMC, FETCH_SIZE x2 per the gfx950 note)",
                            "value": sum(k["fetch_MB"] + k["write_MB"] for k in ig) / max(n_l, 1)}
@@ -261,24 +306,32 @@ def main():
                     "frac": ach / peak, "traffic": traffic, "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
                     "share_of_gpu_time": f["ms"] / tot_ms}
         else:
-            roof = {"bound": "hbm", "kernel": name, "achieved": None, "peak": PEAK_HBM, "unit": "GB/s", "frac": None,
+            # HBM-bound family: algorithmic bytes (every input read once, every output written once) over its time
+            ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f.get("bytes") else None
+            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM if ach else None,
                     "traffic": None, "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
                     "share_of_gpu_time": f["ms"] / tot_ms}
         roof["by_kernel_ms_per_step"] = {k: round(v["ms"] / 3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
-        roof["end_to_end_mfma_frac"] = ips / world * F_IMG / 1e12 / peak
+        # conv FLOP per image of one step: the canonical figure of the workload, or the executed conv FLOPs of the instrumented pass
+        exec_flop_img = sum(f2["flops"] for f2 in fam.values()) / 3.0 / args.bs
+        flop_img = wl["flop_img"] if (wl["flop_img"] and args.size == wl["size"]) else exec_flop_img
+        roof["flop_per_image"] = flop_img
+        roof["flop_per_image_executed"] = exec_flop_img
+        roof["end_to_end_mfma_frac"] = ips / world * flop_img / 1e12 / peak
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(2, args.size, args.cpu_steps)
+        base = cpu_baseline(wl, 2, args.size, args.cpu_steps if args.size <= 640 else 1)
 
     if rank == 0:
         print(json.dumps({
-            "metric": "images/sec at 640x640 bs=16/GPU", "value": ips, "unit": "images/sec", "n_gpus": world,
+            "metric": f"images/sec at {args.size}x{args.size} bs={args.bs}/GPU", "value": ips, "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic", "launch_mode": mode, "loss": loss_val, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
-            "config": {"workload": "YOLOv5-backbone (C3+SPPF) + UNet-lite SegmentHead, fwd+bwd+SGD/EMA step, "
-                                   f"{args.size}x{args.size}, bs={args.bs}/GPU, CE+0.5*Dice, 12 classes (BASELINE configs[1])",
+            "config": {"workload": f"{wl['desc']}, fwd+bwd+SGD/EMA step, {args.size}x{args.size}, bs={args.bs}/GPU, "
+                                   f"CE+0.5*{wl['loss'].capitalize()}, 12 classes ({wl['base']})", "name": args.workload,
                        "global_batch": args.bs * world, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": base}))
     if world > 1:

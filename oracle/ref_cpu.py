@@ -272,6 +272,9 @@ def script_model_forward(sd: SD, cfg: dict, x: torch.Tensor, img_size: Tuple[int
             return c2f(sd, pre, inp, n, add, train=train)
         if kind == "SPPF":
             return sppf(sd, pre, inp, args[1] if len(args) > 1 else 5, act=act, train=train)
+        if kind == "C3_DCNV3":            # C3_DCNV3(c1, c2, n=1, shortcut=True, g=1) — "common and yolo.py":27-38
+            return c3_dcnv3(sd, pre, inp, int(args[1]) if len(args) > 1 else 1, bool(args[2]) if len(args) > 2 else True,
+                            int(args[3]) if len(args) > 3 else 1, train=train)
         if kind == "GAM":
             return gam(sd, pre, inp, train=train)
         if kind in ("Upsample", "nn.Upsample"):

@@ -30,6 +30,27 @@ def script_model_state_shapes(cfg):
             for i in range(n):
                 _conv(sh, f"{pre}.m.{i}", c_, c_, 3)
             return c2
+        if kind == "C3_DCNV3":                  # "common and yolo.py":2-38 + modules/dcnv3.py:50-107
+            c2, n = args[0], int(args[1]) if len(args) > 1 else 1
+            g = int(args[3]) if len(args) > 3 else 1
+            c_ = int(c2 * 0.5)
+            _conv(sh, pre + ".cv1", c1, c_, 1)
+            _conv(sh, pre + ".cv2", c1, c_, 1)
+            _conv(sh, pre + ".cv3", 2 * c_, c2, 1)
+            for i in range(n):
+                b = f"{pre}.m.{i}"
+                _conv(sh, b + ".cv1", c_, c_, 1)
+                _conv(sh, b + ".cv2.conv", c_, c_, 1)
+                d = b + ".cv2.dcnv3"
+                sh[d + ".dw_conv.conv.weight"] = (c_, 1, 3, 3)
+                for k2, v2 in ((".bn.weight", (c_,)), (".bn.bias", (c_,)), (".bn.running_mean", (c_,)), (".bn.running_var", (c_,)),
+                               (".bn.num_batches_tracked", ())):
+                    sh[d + ".dw_conv" + k2] = v2
+                sh[d + ".offset.weight"] = (g * 9 * 2, c_); sh[d + ".offset.bias"] = (g * 9 * 2,)
+                sh[d + ".mask.weight"] = (g * 9, c_); sh[d + ".mask.bias"] = (g * 9,)
+                sh[d + ".input_proj.weight"] = (c_, c_); sh[d + ".input_proj.bias"] = (c_,)
+                sh[d + ".output_proj.weight"] = (c_, c_); sh[d + ".output_proj.bias"] = (c_,)
+            return c2
         if kind == "C2f":
             c2, n = args[0], int(args[1]) if len(args) > 1 else 1
             c = int(c2 * 0.5)

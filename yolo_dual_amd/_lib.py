@@ -156,10 +156,12 @@ def profile_end():
     torch.cuda.synchronize()
     out = []
     for name, e0, e1, g in rec:
-        flops = 0.0
-        if g is not None:
+        flops, nbytes = 0.0, 0.0
+        if isinstance(g, ConvGeom):
             flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.k * g.k * g.Cin
-        d = {"name": name, "ms": e0.elapsed_time(e1), "flops": flops}
+        elif isinstance(g, float):
+            nbytes, g = g, None
+        d = {"name": name, "ms": e0.elapsed_time(e1), "flops": flops, "bytes": nbytes}
         if g is not None:
             d["geom"] = [getattr(g, f) for f, _ in ConvGeom._fields_]
         out.append(d)
@@ -189,4 +191,10 @@ def call(name: str, *args):
     if name in ("ydl_conv_fwd", "ydl_conv_dgrad", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
         src = args[0]._obj
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
+    elif name == "ydl_bn_act_fwd":          # algorithmic bytes: y (+ residual) read once, out written once
+        es = 4 if args[0] == YDL_F32 else 2
+        g = float(args[11]) * args[12] * es * (2 + (1 if args[7] else 0))
+    elif name == "ydl_bn_act_bwd":          # y and dout read once, dy written once (the two-phase kernel reads them twice)
+        es = 4 if args[0] == YDL_F32 else 2
+        g = float(args[22]) * args[24] * es * 3
     _PROFILE.append((name, e0, e1, g))

@@ -24,8 +24,8 @@ import torch.nn as nn
 import yaml
 
 from . import _lib as L
-from .modules import (GAM, BasicBlock, Bottleneck, BottleneckBlock, C2f, C3, C3Common, C3k2, Concat, Conv, MaxPool2d,
-                      SegmentHead, SPPF, Upsample, YdlModule, run_region)
+from .modules import (GAM, BasicBlock, Bottleneck, Bottleneck_DCNV3, BottleneckBlock, C2f, C3, C3_DCNV3, C3Common, C3k2, Concat,
+                      Conv, MaxPool2d, SegmentHead, SPPF, Upsample, YdlModule, run_region)
 from .tape import Tape, Var
 
 LOGGER = logging.getLogger("yolo_dual_amd")
@@ -228,20 +228,20 @@ class _YamlSegModel(YdlModule):
 
 class YOLOv5Seg(_YamlSegModel):
     family = "v5"
-    backbone_modules = {"Conv": Conv, "C3": C3, "SPPF": SPPF}
-    head_modules = {"Conv": Conv, "C3": C3}
+    backbone_modules = {"Conv": Conv, "C3": C3, "SPPF": SPPF, "C3_DCNV3": C3_DCNV3}
+    head_modules = {"Conv": Conv, "C3": C3, "C3_DCNV3": C3_DCNV3}
 
 
 class YOLOv8Seg(_YamlSegModel):
     family = "v8"
-    backbone_modules = {"Conv": Conv, "C2f": C2f, "SPPF": SPPF}
-    head_modules = {"Conv": Conv, "C2f": C2f}
+    backbone_modules = {"Conv": Conv, "C2f": C2f, "SPPF": SPPF, "C3_DCNV3": C3_DCNV3}
+    head_modules = {"Conv": Conv, "C2f": C2f, "C3_DCNV3": C3_DCNV3}
 
 
 class YOLOv9Seg(_YamlSegModel):
     family = "v9"
-    backbone_modules = {"Conv": Conv, "C3k2": C3k2, "SPPF": SPPF}
-    head_modules = {"Conv": Conv, "C2f": C2f, "C3": C3}
+    backbone_modules = {"Conv": Conv, "C3k2": C3k2, "SPPF": SPPF, "C3_DCNV3": C3_DCNV3}
+    head_modules = {"Conv": Conv, "C2f": C2f, "C3": C3, "C3_DCNV3": C3_DCNV3}
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -346,7 +346,7 @@ def make_divisible(x, divisor):
 
 
 _PARSE_TABLE = {"Conv": Conv, "Bottleneck": Bottleneck, "C3": C3Common, "SPPF": SPPF, "Concat": Concat,
-                "nn.Upsample": Upsample, "Upsample": Upsample}
+                "nn.Upsample": Upsample, "Upsample": Upsample, "C3_DCNV3": C3_DCNV3, "Bottleneck_DCNV3": Bottleneck_DCNV3}
 
 
 def parse_model(d: dict, ch: List[int]):
@@ -362,12 +362,12 @@ def parse_model(d: dict, ch: List[int]):
         cls = _PARSE_TABLE[m]
         args = [None if a == "None" else a for a in args]
         n = n_ = max(round(n * gd), 1) if n > 1 else n
-        if cls in (Conv, Bottleneck, C3Common, SPPF):
+        if cls in (Conv, Bottleneck, C3Common, SPPF, C3_DCNV3, Bottleneck_DCNV3):
             c1, c2 = ch[f], args[0]
             if c2 != no:
                 c2 = make_divisible(c2 * gw, 8)
             args = [c1, c2, *args[1:]]
-            if cls is C3Common:
+            if cls in (C3Common, C3_DCNV3):          # models/yolo.py:327-329 + the C3_DCNV3 wiring note ("common and yolo.py")
                 args.insert(2, n)
                 n = 1
         elif cls is Concat:
