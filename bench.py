@@ -229,6 +229,13 @@ def main():
             eager_step, step, mode = step, gstep.step, "hipgraph"
         else:
             ydl.config.set_overlap_wgrad(not args.no_overlap)
+            # drop the captured graphs and their private memory pool, then re-warm the eager path: its first steps after a
+            # capture re-grow the caching allocator's per-stream pools (hundreds of ms of hipMalloc on the big workloads)
+            gstep = None
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            for _ in range(3):
+                step()
         if rank == 0:
             print(f"[bench] eager {t_eager:.2f} ms/step, hipgraph {t_graph:.2f} ms/step -> {mode}", file=sys.stderr)
 

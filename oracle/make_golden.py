@@ -313,6 +313,20 @@ def gen_models_more():
     _model_fixture("model_yolov9seg_64", m9, ns9["SegmentationLoss"](12, 0.0, cw), x, tgt)
 
 
+def gen_resnet50_yaml():
+    """the yaml-driven ResNet50 + UNet-lite head (unet-lite/Resnet50/seg_diceloss_Resnet50.py:382-790 with resnet50.yaml):
+    2-step training trajectory like the other whole-model fixtures"""
+    ns = load_ref("unet-lite/Resnet50/seg_diceloss_Resnet50.py", [(60, 86), (382, 790)])
+    cfg = yaml.safe_load(open(os.path.join(REF, "unet-lite/Resnet50/resnet50.yaml")))
+    cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+    S = 64
+    x = rs_tensor(200, (2, 3, S, S)).abs().clamp(0, 1)
+    tgt = torch.from_numpy(np.random.RandomState(201).randint(0, 12, size=(2, S, S)).astype(np.int64))
+    m = ns["ResNet50Seg"](cfg)
+    m.img_size = [S, S]
+    _model_fixture("model_resnet50yaml_64", m, ns["SegmentationLoss"](12, 0.0, cw), x, tgt)
+
+
 def gen_dcnv3():
     ns = load_ref("models/ops_dcnv3/build/lib.linux-x86_64-cpython-38/functions/dcnv3_func.py", [(92, 189)],
                   extra=dict(DCNv3=None))
@@ -410,6 +424,9 @@ if __name__ == "__main__":
     if "--models-more" in sys.argv:
         gen_models_more()
         sys.exit(0)
+    if "--r50yaml" in sys.argv:
+        gen_resnet50_yaml()
+        sys.exit(0)
     if "--dcnv3" in sys.argv:
         gen_dcnv3()
         gen_dcnv3_module()
@@ -425,3 +442,5 @@ if __name__ == "__main__":
     gen_miou()
     gen_optim()
     gen_models(ns5, ns18)
+    gen_models_more()
+    gen_resnet50_yaml()

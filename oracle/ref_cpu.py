@@ -301,6 +301,64 @@ def script_model_forward(sd: SD, cfg: dict, x: torch.Tensor, img_size: Tuple[int
     return x
 
 
+def resnet50_yaml_forward(sd: SD, cfg: dict, x: torch.Tensor, img_size: Tuple[int, int] = (640, 640), train: bool = True) -> torch.Tensor:
+    """the yaml-driven ``ResNet50Seg`` of unet-lite/Resnet50/seg_diceloss_Resnet50.py:539-710 (resnet50.yaml): ReLU ``Conv``
+    (:389-402), torchvision-style bottlenecks (:405-435), ResNetStem (:438-448), ResNet50Layer (:451-470), a C3 without
+    residual (:522-535); the builder casts its yaml arguments (``C3 [512, False]`` -> n = 0) and the head's ``from`` is absolute."""
+    outs: List[torch.Tensor] = []
+
+    def conv(pre, inp, s=1, p=None, act=True):
+        return conv_bn_act(sd, pre, inp, s=s, p=p, act="relu" if act else "none", train=train)
+
+    for i, (frm, _n, kind, args) in enumerate(cfg["backbone"]):
+        inp = x if frm == -1 else outs[frm]
+        pre = f"backbone.{i}"
+        if kind == "ResNetStem":
+            y = F.max_pool2d(conv(pre + ".stem.0", inp, s=2, p=3), 3, 2, 1)
+        elif kind == "ResNet50Layer":
+            nb, stride = int(args[1]), int(args[2]) if len(args) >= 3 else 1
+            y = inp
+            for b in range(nb):
+                bp = f"{pre}.layer.{b}"
+                st = stride if b == 0 else 1
+                o = conv(bp + ".conv1", y, 1, 0)
+                o = conv(bp + ".conv2", o, st, 1)
+                o = conv(bp + ".conv3", o, 1, 0, act=False)
+                # the down-sampling Conv is registered on the layer and on its first block (same tensors under two names,
+                # :458-463); the layer-level name is the one named_parameters() reports
+                idt = conv(pre + ".downsample", y, st, 0, act=False) if (b == 0 and (pre + ".downsample.conv.weight") in sd) else y
+                y = F.relu(o + idt)
+        else:
+            raise NotImplementedError(kind)
+        outs.append(y)
+        x = y
+    for i, (frm, _n, kind, args) in enumerate(cfg["head"]):
+        inp = [outs[f] for f in frm] if isinstance(frm, list) else outs[frm]
+        pre = f"head.{i}"
+        if kind == "Conv":
+            k = int(args[1]) if len(args) >= 2 else 1
+            s_ = int(args[2]) if len(args) >= 3 else 1
+            y = conv(pre, inp, s_, None, act=args[5] if len(args) >= 6 else True)
+        elif kind == "C3":
+            n = int(args[1]) if len(args) >= 2 else 1
+            y = c3_script(sd, pre, inp, n, False, act="relu", train=train)
+        elif kind == "SPPF":
+            y = sppf(sd, pre, inp, int(args[1]) if len(args) >= 2 else 5, act="relu", train=train)
+        elif kind == "Upsample":
+            y = F.interpolate(inp, scale_factor=float(args[1]) if len(args) >= 2 else 2.0, mode="nearest")
+        elif kind == "Concat":
+            y = concat_align(inp, 1)
+        elif kind == "nn.Softmax":
+            y = torch.softmax(inp, 1)
+        else:
+            raise NotImplementedError(kind)
+        outs.append(y)
+        x = y
+    if tuple(x.shape[2:]) != tuple(img_size):
+        x = F.interpolate(x, size=tuple(img_size), mode="bilinear", align_corners=False)
+    return x
+
+
 # --------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------

@@ -114,3 +114,54 @@ def resnet_seg_state_shapes(kind, nc):
     _conv(sh, "head.final_conv.0", 384, 256, 3)
     _conv(sh, "head.final_conv.1", 256, nc, 1)
     return sh
+
+
+def resnet50_yaml_state_shapes(cfg):
+    """yaml-driven ResNet50Seg (unet-lite/Resnet50/seg_diceloss_Resnet50.py:438-668).  Returns (shapes, aliases): the layer's
+    down-sampling Conv appears under ``backbone.i.downsample`` and again under ``backbone.i.layer.0.downsample`` (one module,
+    two names); ``aliases`` maps the second name to the first."""
+    sh, alias = OrderedDict(), {}
+    chs, prev = [], 3
+    for i, (frm, _n, kind, args) in enumerate(cfg["backbone"]):
+        c1 = prev if frm == -1 else chs[frm]
+        pre = f"backbone.{i}"
+        if kind == "ResNetStem":
+            out = int(args[0])
+            _conv(sh, pre + ".stem.0", 3, out, 7)
+        else:
+            out, nb, stride = int(args[0]), int(args[1]), int(args[2]) if len(args) >= 3 else 1
+            mid = out // 4
+            has_ds = stride != 1 or c1 != out
+            if has_ds:
+                _conv(sh, pre + ".downsample", c1, out, 1)
+            inc = c1
+            for b in range(nb):
+                bp = f"{pre}.layer.{b}"
+                _conv(sh, bp + ".conv1", inc, mid, 1)
+                _conv(sh, bp + ".conv2", mid, mid, 3)
+                _conv(sh, bp + ".conv3", mid, out, 1)
+                if b == 0 and has_ds:
+                    _conv(sh, bp + ".downsample", c1, out, 1)
+                    for suf in (".conv.weight", ".bn.weight", ".bn.bias", ".bn.running_mean", ".bn.running_var", ".bn.num_batches_tracked"):
+                        alias[bp + ".downsample" + suf] = pre + ".downsample" + suf
+                inc = out
+        chs.append(out)
+        prev = out
+    for i, (frm, _n, kind, args) in enumerate(cfg["head"]):
+        c1 = sum(chs[f] for f in frm) if isinstance(frm, list) else chs[frm]
+        pre = f"head.{i}"
+        if kind == "Conv":
+            out = int(args[0])
+            _conv(sh, pre, c1, out, int(args[1]) if len(args) >= 2 else 1)
+        elif kind == "C3":
+            out, n = int(args[0]), int(args[1]) if len(args) >= 2 else 1
+            c_ = int(out * 0.5)
+            _conv(sh, pre + ".cv1", c1, c_, 1)
+            _conv(sh, pre + ".cv2", c1, c_, 1)
+            _conv(sh, pre + ".cv3", 2 * c_, out, 1)
+            for j in range(n):
+                _conv(sh, f"{pre}.m.{j}", c_, c_, 3)
+        else:
+            out = c1
+        chs.append(out)
+    return sh, alias

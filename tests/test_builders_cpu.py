@@ -80,3 +80,31 @@ def test_conv_signature_variants():
         ydl.Conv(8, 8, 1, 1, None, 3)
     w = ydl.Conv(8, 16, 3).conv.weight
     assert w.shape == (16, 8, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()   # OIHW logical, KRSC physical
+
+
+def test_resnet50_yaml_builder_state_dict_layout():
+    """state_dict names/shapes/order of the yaml-driven ResNet50Seg equal the reference builder's (seg_diceloss_Resnet50.py:570-668):
+    the layer-level down-sampling Conv is listed twice (layer and first block share it), C3 [c, False] has no inner convs"""
+    import os
+    import yaml
+    import yolo_dual_amd as ydl
+    from tests.model_shapes import resnet50_yaml_state_shapes
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg", "resnet50_seg.yaml")))
+    m = ydl.ResNet50SegYaml(cfg)
+    shapes, alias = resnet50_yaml_state_shapes(cfg)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    for k, k0 in alias.items():
+        assert sd[k].data_ptr() == sd[k0].data_ptr()
+    assert not any(k.startswith("head.4.m.") for k in sd)           # C3 [512, False]: n = int(False) = 0
+    assert isinstance(m.head[0].act, __import__("torch").nn.ReLU)
+
+
+def test_c3_dcnv3_builders():
+    """C3_DCNV3 resolves in the script builders (C3_DCNV3(c1, *args)) and in parse_model (n inserted like C3)"""
+    import yolo_dual_amd as ydl
+    d = {"nc": 12, "depth_multiple": 1.0, "width_multiple": 1.0,
+         "backbone": [[-1, 1, "Conv", [16, 3, 2]], [-1, 2, "C3_DCNV3", [16]]], "head": [[-1, 1, "Conv", [12, 1, 1]]]}
+    seq, save = ydl.parse_model(d, [3])
+    assert type(seq[1]).__name__ == "C3_DCNV3" and len(seq[1].m) == 2 and type(seq[1].m[0].cv2.dcnv3).__name__ == "DCNv3"

@@ -331,6 +331,23 @@ def test_model_resnet50seg():
                  dict(class_weights=None, kind="dice"))
 
 
+def test_model_resnet50_yaml():
+    """the yaml-driven ResNet50 + UNet-lite head (unet-lite/Resnet50/seg_diceloss_Resnet50.py:438-710, resnet50.yaml): ReLU Convs,
+    argument-casting builder (C3 [512, False] -> n = 0), absolute head indices"""
+    import os
+    from tests.model_shapes import resnet50_yaml_state_shapes
+    g = Golden("model_resnet50yaml_64")
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg", "resnet50_seg.yaml")))
+    shapes, alias = resnet50_yaml_state_shapes(cfg)
+
+    def mk():
+        sd = {}
+        for k, s_ in shapes.items():
+            sd[k] = sd[alias[k]] if k in alias else (torch.zeros(s_) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64))
+        return sd
+    _model_check(g, lambda sd, x: R.resnet50_yaml_forward(sd, cfg, x, (64, 64)), mk, dict(class_weights=CW, kind="dice"))
+
+
 def test_model_yolov9seg():
     """BASELINE config 5 family (C3k2 + GAM + SPPF backbone); the fixture was generated with `GAM []` because the
     reference cannot build its own yaml's `GAM [512]` (GAM(c1, 512) is a TypeError)"""

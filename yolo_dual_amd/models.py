@@ -221,6 +221,13 @@ class _YamlSegModel(YdlModule):
     def _initialize_weights(self) -> None:
         _kaiming_init(self, self.init_nonlinearity)
 
+    def fuse(self):
+        """models/yolo.py:140-148: fold every Conv's BatchNorm into its convolution (inference only)"""
+        for m in self.modules():
+            if isinstance(m, Conv) and not m.depthwise:
+                m.fuse()
+        return self
+
     def _log_model_info(self) -> None:
         n = sum(p.numel() for p in self.parameters())
         LOGGER.info("model: %s parameters, %d classes", f"{n:,}", self.num_classes)
@@ -336,6 +343,173 @@ class ResNet50Seg(_ResNetSeg):
     ``F.interpolate(size=(640, 640), bilinear, align_corners=False)`` whatever the input size"""
     backbone_cls = ResNet50
     fixed_out = (640, 640)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# yaml-driven ResNet50 + UNet-lite head (unet-lite/Resnet50/seg_diceloss_Resnet50.py:389-710, resnet50.yaml)
+# ----------------------------------------------------------------------------------------------------------
+class ConvReLU(Conv):
+    """that script's ``Conv(c1, c2, k=1, s=1, p=None, g=1, act=True)``: Conv2d -> BatchNorm2d -> **ReLU** (:389-402)"""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__(c1, c2, k, s, p, g, nn.ReLU(inplace=True) if act is True else (act if isinstance(act, nn.Module) else False))
+
+
+class BottleneckBlockReLU(BottleneckBlock):
+    """:405-435 — the torchvision bottleneck with ReLU ``Conv`` blocks"""
+
+    def __init__(self, in_channels, mid_channels, stride=1, downsample=None):
+        YdlModule.__init__(self)
+        self.conv1 = ConvReLU(in_channels, mid_channels, 1, 1, 0, act=True)
+        self.conv2 = ConvReLU(mid_channels, mid_channels, 3, stride, 1, act=True)
+        self.conv3 = ConvReLU(mid_channels, mid_channels * self.expansion, 1, 1, 0, act=False)
+        self.downsample = downsample
+        self.act = nn.ReLU(inplace=True)
+
+
+class ResNetStem(YdlModule):
+    """:438-448: 7x7/s2 Conv + 3x3/s2 max-pool"""
+
+    def __init__(self, out_channels: int):
+        super().__init__()
+        self.stem = nn.Sequential(ConvReLU(3, out_channels, 7, 2, 3), MaxPool2d(3, 2, 1))
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        return self.stem[1]._fwd(tape, self.stem[0]._fwd(tape, x))
+
+
+class ResNet50Layer(YdlModule):
+    """:451-470: ``num_blocks`` bottlenecks; the down-sampling Conv is registered on the layer AND on its first block (the
+    reference's state_dict therefore lists it under both names — kept, so that checkpoints interchange)"""
+
+    def __init__(self, in_channels: int, out_channels: int, num_blocks: int, stride: int = 1):
+        super().__init__()
+        mid = out_channels // BottleneckBlockReLU.expansion
+        self.downsample = None
+        if stride != 1 or in_channels != out_channels:
+            self.downsample = ConvReLU(in_channels, out_channels, 1, stride, 0, act=False)
+        blocks = [BottleneckBlockReLU(in_channels, mid, stride, self.downsample)]
+        for _ in range(1, num_blocks):
+            blocks.append(BottleneckBlockReLU(out_channels, mid))
+        self.layer = nn.Sequential(*blocks)
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        for blk in self.layer:
+            x = blk._fwd(tape, x)
+        return x
+
+
+class C3Plain(YdlModule):
+    """that script's C3 (:522-535): cv3(cat(m(cv1 x), cv2 x)) with ReLU Convs and NO residual whatever ``shortcut`` says"""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = self.c_ = int(c2 * e)
+        self.cv1 = ConvReLU(c1, self.c, 1, 1)
+        self.cv2 = ConvReLU(c1, self.c, 1, 1)
+        self.cv3 = ConvReLU(2 * self.c, c2, 1, 1)
+        self.m = nn.Sequential(*(ConvReLU(self.c, self.c, 3, 1, g=g) for _ in range(n)))
+
+    def _fwd(self, tape: Tape, x: Var) -> Var:
+        from .modules import _csp_forward
+        return _csp_forward(self, tape, x, False)
+
+
+class SPPFReLU(SPPF):
+    def __init__(self, c1, c2, k=5):
+        YdlModule.__init__(self)
+        c_ = c1 // 2
+        self.cv1 = ConvReLU(c1, c_, 1, 1)
+        self.cv2 = ConvReLU(c_ * 4, c2, 1, 1)
+        self.k, self.c_ = k, c_
+
+
+def parse_none(value):
+    """:76-85: the yaml's ``None`` / ``none`` strings become Python None (recursively)"""
+    if isinstance(value, str) and value.lower() == "none":
+        return None
+    if isinstance(value, list):
+        return [parse_none(v) for v in value]
+    if isinstance(value, dict):
+        return {k: parse_none(v) for k, v in value.items()}
+    return value
+
+
+class ResNet50SegYaml(_YamlSegModel):
+    """``ResNet50Seg`` of unet-lite/Resnet50/seg_diceloss_Resnet50.py:539-710: ResNetStem / ResNet50Layer backbone rows and a
+    UNet-lite head whose builder CASTS its yaml arguments (``C3 [512, False]`` -> n = int(False) = 0, no residual; Upsample
+    ``[None, 2, 'nearest']`` -> scale_factor 2.0), ReLU everywhere, the head's ``from`` absolute (resnet50.yaml:23-38)."""
+    family = "r50"
+    init_nonlinearity = "relu"
+
+    def __init__(self, cfg, num_classes: Optional[int] = None):
+        if not isinstance(cfg, str):
+            cfg = parse_none(cfg)
+        super().__init__(cfg, num_classes)
+        if isinstance(self.yaml, dict):
+            self.yaml = parse_none(self.yaml)
+        self.stride = torch.tensor([4, 8, 16, 32])
+
+    def _build_backbone(self, cfg):
+        cfg = parse_none(cfg)
+        backbone, out_chs, prev = nn.ModuleList(), [], 3
+        for from_, _num, module, args in cfg:
+            c1 = prev if from_ == -1 else out_chs[from_]
+            if module == "ResNetStem":
+                out_ch = int(args[0])
+                layer = ResNetStem(out_ch)
+            elif module == "ResNet50Layer":
+                out_ch = int(args[0])
+                layer = ResNet50Layer(c1, out_ch, int(args[1]), int(args[2]) if len(args) >= 3 else 1)
+            else:
+                raise NotImplementedError(f"Backbone unknown module: {module}")
+            backbone.append(layer)
+            out_chs.append(out_ch)
+            prev = out_ch
+        return backbone, out_chs
+
+    def _build_head(self, cfg, backbone_out_chs):
+        cfg = parse_none(cfg)
+        head, all_chs = nn.ModuleList(), list(backbone_out_chs)
+        for from_, _num, module, args in cfg:
+            c1 = sum(all_chs[f] for f in from_) if isinstance(from_, list) else all_chs[from_]
+            if module == "Conv":
+                out_ch = int(args[0])
+                k = int(args[1]) if len(args) >= 2 else 1
+                s_ = int(args[2]) if len(args) >= 3 else 1
+                p_ = int(args[3]) if (len(args) >= 4 and args[3] is not None) else None
+                g = int(args[4]) if len(args) >= 5 else 1
+                act = args[5] if len(args) >= 6 else True
+                layer = ConvReLU(c1, out_ch, k, s_, p_, g, act)
+            elif module == "SPPF":
+                out_ch = int(args[0])
+                layer = SPPFReLU(c1, out_ch, int(args[1]) if len(args) >= 2 else 5)
+            elif module == "Upsample":
+                size = args[0] if len(args) >= 1 else None
+                sf = args[1] if len(args) >= 2 else 2.0
+                mode = args[2] if len(args) >= 3 else "nearest"
+                if sf is not None:
+                    sf = float(sf)
+                if size is not None and sf is not None:
+                    size = None
+                layer = Upsample(size=size, scale_factor=sf, mode=mode, align_corners=False if mode != "nearest" else None)
+                out_ch = c1
+            elif module == "Concat":
+                layer = Concat(int(args[0]) if len(args) >= 1 else 1)
+                out_ch = c1
+            elif module == "C3":
+                out_ch = int(args[0])
+                n = int(args[1]) if len(args) >= 2 else 1
+                layer = C3Plain(c1, out_ch, n, bool(args[2]) if len(args) >= 3 else False, int(args[3]) if len(args) >= 4 else 1,
+                                float(args[4]) if len(args) >= 5 else 0.5)
+            elif module == "nn.Softmax":
+                layer = Softmax(int(args[0]) if len(args) >= 1 else 1)
+                out_ch = c1
+            else:
+                raise NotImplementedError(f"head unknown module: {module}")
+            head.append(layer)
+            all_chs.append(out_ch)
+        return head, all_chs
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -327,6 +327,9 @@ class Conv(YdlModule):
                 raise NotImplementedError("depth-wise Conv with a fused residual")
             y = tape.dwconv_bn_act(x, self, act)
             return y if out is None else tape.copy(y, out)
+        if getattr(self, "_fused", None) is not None and not tape.train:
+            y = tape.conv_bias_act(x, self, act, res=res, res_mode=res_mode)
+            return y if out is None else tape.copy(y, out)
         if (x.ext_src is not None and x.real is None and not x.need and config.stem_s2d() and res is None and self.s > 1
                 and self.k % self.s == 0 and self.p % self.s == 0 and self.c1 * self.s * self.s <= 16
                 and x.H % self.s == 0 and x.W % self.s == 0):
@@ -335,8 +338,39 @@ class Conv(YdlModule):
             return tape.conv_bn_act(tape.input_s2d(x.ext_src, self.s), ad, 1, ad.p, act, out=out)
         return tape.conv_bn_act(x, self, self.s, self.p, act, out=out, res=res, res_mode=res_mode)
 
+    # -- inference-time Conv+BN folding (models/common.py:61-64, utils/torch_utils.py:248-269, models/yolo.py:140-148) --
+    def fuse(self) -> "Conv":
+        """fold the BatchNorm running statistics into the convolution: eval-mode forward becomes act(conv(x, w') + b')"""
+        if self.depthwise:
+            raise NotImplementedError("fuse() of a depth-wise Conv")
+        from .checkpoint import fuse_conv_and_bn
+        wf, bf = fuse_conv_and_bn(self.conv, self.bn)
+        cp = round_up(self.c2, 8)
+        bias = torch.zeros(cp, dtype=torch.float32, device=wf.device)
+        bias[:self.c2] = bf
+        self._fused = {"w": wf.permute(0, 2, 3, 1).contiguous(), "bias": bias, "ones": torch.ones(cp, dtype=torch.float32, device=wf.device),
+                       "cw": {}}
+        return self
+
+    def unfuse(self) -> "Conv":
+        self._fused = None
+        return self
+
     def forward_fuse(self, x):
-        raise NotImplementedError("inference-time Conv+BN folding is out of scope (SURVEY §8f-2)")
+        if getattr(self, "_fused", None) is None:
+            self.fuse()
+        return self.forward(x)
+
+    def _fused_weights(self, tape: Tape):
+        f = self._fused
+        cw = f["cw"].get(tape.dname)
+        if cw is None:
+            kk = self.k * self.k
+            w = torch.empty((self.c2, kk, round_up(self.c1, 8)), dtype=tape.tdt, device=f["w"].device)
+            wt = torch.empty((self.c1, kk, round_up(self.c2, 8)), dtype=tape.tdt, device=f["w"].device)
+            L.call("ydl_weight_prep", tape.dt, _p(f["w"]), _p(w), _p(wt), self.c2, kk, self.c1, _stream())
+            cw = f["cw"][tape.dname] = (w, wt)
+        return cw
 
 
 class _S2DStem:

@@ -138,14 +138,24 @@ class FlatSGDEMA(torch.optim.Optimizer):
         if self.ema_arena is not None:
             self.updates += 1
             d = self.ema_decay * (1.0 - math.exp(-self.updates / self.ema_tau))
-        if getattr(self, "_hyper_host", None) is None:
-            self._hyper_host = torch.empty(7, dtype=torch.float32).pin_memory()
+        if getattr(self, "_hyper_ring", None) is None:
+            # ring of pinned staging buffers, each guarded by the event of its last H2D copy: the host never rewrites a
+            # buffer whose copy may still be queued behind a graph replay (one reused buffer raced with the next step's write)
+            self._hyper_ring = [(torch.empty(7, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._hyper_slot = 0
+            self._hyper_used = [False] * 8
             self._hyper_dev = torch.empty(7, dtype=torch.float32, device=self.params_arena.device)
-        h = self._hyper_host
+        i = self._hyper_slot
+        self._hyper_slot = (i + 1) % len(self._hyper_ring)
+        h, ev = self._hyper_ring[i]
+        if self._hyper_used[i]:
+            ev.synchronize()              # normally long complete (8 steps ago)
         h[0], h[1], h[2] = lr_w, lr_bn, lr_bias
         h[3], h[4] = self.param_groups[1]["momentum"], self.param_groups[1]["weight_decay"]
         h[5], h[6] = grad_scale, d
         self._hyper_dev.copy_(h, non_blocking=True)
+        ev.record()
+        self._hyper_used[i] = True
 
     @torch.no_grad()
     def step_device_hyper(self) -> None:
@@ -219,6 +229,49 @@ class FlatSGDEMA(torch.optim.Optimizer):
                    0.0, 0.0, mom, 0.0, 1.0, 0, d, st)
         config.bump_weight_epoch()
         return None
+
+    # ------------------------------------------------------------------ checkpoint state (seg_diceloss_yolov5.py:1204-1212)
+    def state_dict(self):
+        """what ``'optimizer': optimizer.state_dict()`` of a checkpoint holds here: hyper-parameters per group, the momentum
+        arena, which parameters already own a momentum buffer, and the EMA update counter (plain tensors / numbers only, so
+        the file loads with ``torch.load(..., weights_only=True)``)"""
+        return {"format": "ydl-flat-sgd-ema-1",
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "momentum": self.mom_arena.detach().cpu().clone(),
+                "has_momentum": torch.tensor([bool(self._has_buf.get(id(p), False)) for p, *_ in self._slots]),
+                "updates": int(self.updates)}
+
+    def load_state_dict(self, sd) -> None:
+        if sd.get("format") != "ydl-flat-sgd-ema-1":
+            raise ValueError("optimizer state was not written by yolo_dual_amd.FlatSGDEMA")
+        if sd["momentum"].numel() != self.mom_arena.numel():
+            raise ValueError("optimizer state belongs to a different model (arena size differs)")
+        for g, gs in zip(self.param_groups, sd["param_groups"]):
+            g.update(gs)
+        self.mom_arena.copy_(sd["momentum"].to(self.mom_arena.device))
+        for (p, *_), h in zip(self._slots, sd["has_momentum"].tolist()):
+            self._has_buf[id(p)] = bool(h)
+        self.updates = int(sd.get("updates", 0))
+
+    def load_ema_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """restore the EMA shadow from a ``state_dict`` (smart_resume: ``ema.ema.load_state_dict(ckpt['ema']...)``)"""
+        if self.ema_arena is None:
+            raise RuntimeError("EMA disabled")
+        cur = self.ema_state_dict()
+        by_ptr = {}
+        for p, off, n, _g in self._slots:
+            by_ptr[p.data_ptr()] = (off, n)
+        for b, off, n in self._buf_slots:
+            by_ptr[b.data_ptr()] = (off, n)
+        for k, v in self.model.state_dict().items():
+            slot = by_ptr.get(v.data_ptr())
+            if slot is None or not v.dtype.is_floating_point or k not in sd or tuple(sd[k].shape) != tuple(cur[k].shape):
+                continue
+            off, n = slot
+            src = sd[k].float().to(self.ema_arena.device)
+            if v.dim() == 4:
+                src = src.permute(0, 2, 3, 1).contiguous()
+            self.ema_arena[off:off + n].copy_(src.reshape(-1))
 
     # ------------------------------------------------------------------ EMA access (ModelEMA.ema equivalent)
     def ema_state_dict(self) -> Dict[str, torch.Tensor]:

@@ -479,6 +479,26 @@ class Tape:
         self.bw.append(bw)
         return ret
 
+    def conv_bias_act(self, x: Var, m, act: int, res: Optional[Var] = None, res_mode: int = L.RES_NONE) -> Var:
+        """eval-only folded Conv (``Conv.forward_fuse``, models/common.py:61-64): act(conv(x, w') + b') [+ res]"""
+        if self.record:
+            raise RuntimeError("a fused (BN-folded) Conv is inference-only")
+        x = self._flat(x)
+        if res is not None:
+            res = self._flat(res)
+        k, s, p = m.k, m.s, m.p
+        Ho = (x.H + 2 * p - k) // s + 1
+        Wo = (x.W + 2 * p - k) // s + 1
+        out = self.new(x.N, m.c2, Ho, Wo)
+        w, _wt = m._fused_weights(self)
+        geom = L.ConvGeom(x.N, x.H, x.W, m.c1, Ho, Wo, m.c2, k, s, p, x.ld, out.ld, 0)
+        st = _stream()
+        L.call("ydl_conv_fwd", ctypes.byref(geom), self.dt, _p(x.t), _p(w), _p(out.t), None, 0, st)
+        f = m._fused
+        L.call("ydl_bn_act_fwd", self.dt, _p(out.t), out.ld, _p(f["ones"]), _p(f["bias"]), _p(res.t) if res is not None else None,
+               res.ld if res is not None else 0, res_mode, act, _p(out.t), out.ld, x.N * Ho * Wo, round_up(m.c2, 8), st)
+        return out
+
     def _bw_split(self, m, subs, dy: Var, wt: torch.Tensor, Cout_p: int, Ho: int, Wo: int, st2) -> None:
         """backward of the commuted conv-over-concat: per source one wgrad into its column block of the weight gradient
         and one dgrad with its row block of wt; the resized source sees d z = bilinear_up^T (dy)."""
