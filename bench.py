@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the side stream (wgrad / dead branch) into the graphs too")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient exchange: RCCL all-reduce (default) or the hand-rolled reduce-scatter + all-gather over all peers")
+    ap.add_argument("--dp-wire", default="f32", choices=["f32", "bf16"], help="wire format of the gradients")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -166,7 +169,7 @@ def main():
     # The throughput run steps the optimizer every batch (accumulate = 1; the reference would accumulate
     # round(64/16) = 4 batches at bs 16), which is what the formula is evaluated with here.
     opt = ydl.FlatSGDEMA(model, lr=0.01, momentum=0.937, weight_decay=5e-4 * args.bs * world / 64.0, ema=(rank == 0))
-    dp = DataParallel(model, opt) if world > 1 else None
+    dp = DataParallel(model, opt, algo=args.dp_algo, wire=args.dp_wire) if world > 1 else None
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     imgs = torch.rand(args.bs, 3, args.size, args.size, device=dev, generator=g)

@@ -264,6 +264,11 @@ int ydl_group_softmax_bwd(int dtype, const void* y, int ldy, const void* dy, int
 /* dst[p][0:C] (+)= (compute dtype) src[p][0:C]; src f32 (the DCNv3 op returns f32 gradients, dcnv3_cuda.cu:126-133) */
 int ydl_cast_f32(int dtype, const float* src, int lds, void* dst, int ldd, int64_t npix, int C, int accumulate, void* stream);
 
+/* ---- gradient transport helpers (yolo_dual_amd.parallel: reduce-scatter + all-gather over all peers, bf16 wire) ---------
+ * dst[i] = sum over r < nchunks of src[r][i] in that fixed order (src f32 or bf16, dst f32);  dst (+)= (f32) src */
+int ydl_reduce_chunks(int dtype, const void* src, float* dst, int64_t n, int nchunks, void* stream);
+int ydl_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,7 @@
 
 TEST INFRASTRUCTURE (build container; ~2 minutes on 8 cores).  YOLOv5Seg (script C3 blocks, yolov5_seg.yaml) from a seeded
 fill, 128x128 synthetic blobby masks, batch 8 cycling over 16 batches, CE + 0.5*Dice with weight.yaml's class
-weights, SGD-nesterov lr 0.02 / momentum 0.937, 300 steps, then the mIoU of val_diceloss.py:37-75 (eval-mode BN) on a
+weights, SGD-nesterov lr 0.02 decaying linearly to 0.001 / momentum 0.937, 600 steps, then the mIoU of val_diceloss.py:37-75 (eval-mode BN) on a
 held-out batch.  Stored: per-step losses, the validation mIoU every 25 steps, the final per-class IoUs.  The oracle
 (oracle/ref_cpu.py) is pinned to the reference's own classes by tests/test_oracle_golden.py."""
 import os
@@ -19,7 +19,8 @@ from oracle import ref_cpu as R  # noqa: E402
 from oracle.fill import fill_state_dict  # noqa: E402
 from tests.model_shapes import script_model_state_shapes  # noqa: E402
 
-S, BS, STEPS, LR, NB = 128, 8, 300, 0.02, 16
+S, BS, STEPS, LR, NB = 128, 8, 600, 0.02, 16
+LRF = 0.05          # linear decay of the learning rate to LRF * LR over the run (the reference's LambdaLR shape, :976-980)
 CW = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
 
 
@@ -61,7 +62,7 @@ def main():
         losses.append(float(total.detach()))
         for k in pnames:
             if ps[k].grad is not None:
-                bufs[k] = R.sgd_nesterov_step(sd[k], ps[k].grad, bufs.get(k), LR, 0.937, 0.0)
+                bufs[k] = R.sgd_nesterov_step(sd[k], ps[k].grad, bufs.get(k), LR * (1.0 - (1.0 - LRF) * st / STEPS), 0.937, 0.0)
         for k in sd:
             if k not in ps:
                 sd[k] = run[k]
@@ -72,7 +73,7 @@ def main():
             mious.append(miou)
             print(f"step {st + 1}: loss {losses[-1]:.4f}  val mIoU {miou:.4f}", flush=True)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_curve_yolov5seg_128.npz"), losses=np.array(losses),
-                        mious=np.array(mious), final_ious=np.array(ious), hyp=np.array([S, BS, STEPS, LR, NB]))
+                        mious=np.array(mious), final_ious=np.array(ious), hyp=np.array([S, BS, STEPS, LR, NB, LRF]))
 
 
 if __name__ == "__main__":

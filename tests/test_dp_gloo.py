@@ -26,7 +26,7 @@ def _build():
     return nn.Sequential(ydl.Conv(8, 16, 3, 1), ydl.C3(16, 16, 1), ydl.Conv(16, 8, 1, 1), ydl.Conv(8, 8, 1, 1))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algo="allreduce", wire="f32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
                 for p in net.parameters():
                     p.add_(1.0)
         opt = FlatSGDEMA(net, lr=0.1)
-        dp = DataParallel(net, opt, bucket_bytes=4096)      # tiny buckets -> several of them
+        dp = DataParallel(net, opt, bucket_bytes=4096, algo=algo, wire=wire)      # tiny buckets -> several of them
         ref0 = [torch.zeros_like(opt.params_arena) for _ in range(world)]
         dist.all_gather(ref0, opt.params_arena)
         assert torch.equal(ref0[0], ref0[1]), "broadcast did not equalise the replicas"
@@ -67,7 +67,8 @@ def _worker(rank, world, port, q):
                     assert float(got.abs().max()) == 0.0       # dead ranges are neither written nor reduced
                 else:
                     want = sum(r + 1 for r in range(world)) * (1.0 + 0.001 * torch.arange(n, dtype=torch.float32) + step)
-                    assert torch.allclose(got, want, rtol=1e-6), (step, off)
+                    # bf16 wire: one rounding on the way out and one on the way back (rs_ag sums in f32 in between)
+                    assert torch.allclose(got, want, rtol=1e-6 if wire == "f32" else 2e-2), (step, off)
             if step == 0:
                 plan = dp.reducer._plan
                 assert plan is not None and len(plan) >= 2
@@ -77,6 +78,10 @@ def _worker(rank, world, port, q):
             if step == 1:
                 # second step: every bucket was launched from the hooks before finish()
                 assert all(v == 0 for v in dp.reducer._pending.values())
+            # every rank ends with bit-identical gradients (the replicas must not drift apart)
+            allg = [torch.zeros_like(opt.grads_arena) for _ in range(world)]
+            dist.all_gather(allg, opt.grads_arena)
+            assert all(torch.equal(allg[0], t) for t in allg[1:]), "ranks disagree on the reduced gradients"
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -85,17 +90,36 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_bucket_reducer_two_ranks():
+def _run(world, algo="allreduce", wire="f32"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, algo, wire)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_bucket_reducer_two_ranks():
+    _run(2)
+
+
+def test_bucket_reducer_four_ranks():
+    _run(4)
+
+
+@pytest.mark.parametrize("world,wire", [(2, "f32"), (4, "f32"), (4, "bf16")])
+def test_reduce_scatter_all_gather_over_all_peers(world, wire):
+    """the hand-rolled comparator of RCCL's all-reduce: every rank trades 1/world of each bucket with every peer at
+    once, sums in f32 in rank order, and returns its reduced piece to every peer"""
+    _run(world, algo="rs_ag", wire=wire)
+
+
+def test_bf16_wire_all_reduce():
+    _run(2, algo="allreduce", wire="bf16")
 
 
 def test_flat_arena_layout_and_state_dict_roundtrip():

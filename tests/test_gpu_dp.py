@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, use_graph, q):
+def _worker(rank, world, port, use_graph, q, algo="allreduce", wire="f32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, use_graph, q):
         m.load_state_dict(sd)
         m = m.cuda().train()
         opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.937, weight_decay=5e-4, ema=(rank == 0))
-        dp = DataParallel(m, opt, bucket_bytes=1 << 20)
+        dp = DataParallel(m, opt, bucket_bytes=1 << 20, algo=algo, wire=wire)
         cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
         crit = ydl.SegmentationLoss(12, 0.0, cw, "dice", sync=False)
         gen = torch.Generator("cuda").manual_seed(100 + rank)      # different data per rank
@@ -90,12 +90,15 @@ def _worker(rank, world, port, use_graph, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_rank_data_parallel_on_one_gpu(use_graph):
+@pytest.mark.parametrize("use_graph,algo,wire", [(False, "allreduce", "f32"), (True, "allreduce", "f32"), (False, "rs_ag", "f32"),
+                                                 (False, "rs_ag", "bf16"), (True, "rs_ag", "bf16")])
+def test_two_rank_data_parallel_on_one_gpu(use_graph, algo, wire):
+    """two ranks on one MI355X (gloo transport): RCCL-style all-reduce, and the hand-rolled reduce-scatter + all-gather over all
+    peers with f32 / bf16 wire format (the HIP cast / chunk-sum kernels run here), eager and replayed from HIP graphs"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, q, algo, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=280) for _ in procs]

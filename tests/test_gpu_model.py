@@ -23,12 +23,12 @@ def _cfg(name, swap):
     return cfg
 
 
-def _train_check(g, model, crit, mode, steps=2, lr=0.01, f32_grad_tol=2e-3, later_loss_tol=None):
+def _train_check(g, model, crit, mode, steps=2, lr=0.01, f32_grad_tol=2e-3, later_loss_tol=None, f32_out_tol=1e-4):
     import yolo_dual_amd as ydl
     ydl.set_compute_dtype(mode)
     # bf16 at this toy size (64x64, batch 2: the deepest BatchNorms see 8 values per channel) only checks the loss and
     # the dead-parameter set; bf16 accuracy at a realistic size is test_bf16_tracks_f32 below
-    tol = dict(f32=dict(out=1e-4, loss=1e-4, gn=f32_grad_tol, fin=f32_grad_tol),
+    tol = dict(f32=dict(out=f32_out_tol, loss=1e-4, gn=f32_grad_tol, fin=f32_grad_tol),
                bf16=dict(out=None, loss=5e-2, gn=None, fin=None))[mode]
     sd = model.state_dict()
     fill_state_dict(sd, 1234, bn_stats=False)
@@ -119,9 +119,11 @@ def test_resnet50_yaml_trajectory(mode):
     g = Golden("model_resnet50yaml_64")
     m = ydl.ResNet50SegYaml(_cfg("resnet50_seg.yaml", {}))
     m.img_size = [64, 64]
-    # 53 convolutions on a 64x64 input (BatchNorm over 8-32 values in the deep layers): gradient norms reproduce to ~1 % in fp32
-    # (see test_resnet50seg_trajectory); logits and the first loss hold 1e-4
-    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode, f32_grad_tol=1e-2, later_loss_tol=1e-3)
+    # 53 convolutions on a 64x64 input: the deepest BatchNorms normalise over 8 values (2x2 pixels, batch 2), and fp32 itself is
+    # only reproducible to 3.4e-4 on the output probabilities here (CPU oracle in f32 vs the same oracle in f64; the f32 oracle
+    # equals the reference fixture bit for bit) — this path lands at 3.2e-4.  Hence 1e-3 on the outputs and 1e-2 on gradient norms
+    # (see test_resnet50seg_trajectory); the loss, an average over all pixels, still holds 1e-4.
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode, f32_grad_tol=1e-2, later_loss_tol=1e-3, f32_out_tol=1e-3)
 
 
 @pytest.mark.parametrize("mode", ["f32"])

@@ -1,7 +1,7 @@
 """Training-dynamics parity (north_star: "mIoU within +-0.1 of reference").
 
 1. ``test_training_run_reaches_the_oracle_miou``: a run that actually learns — YOLOv5Seg, 128x128 blobby masks,
-   batch 8 cycling over 16 batches, CE + 0.5*Dice, SGD-nesterov, 300 steps — replayed on the HIP path in parity (f32) and
+   batch 8 cycling over 16 batches, CE + 0.5*Dice, SGD-nesterov with a linearly decaying learning rate, 600 steps — replayed on the HIP path in parity (f32) and
    throughput (bf16) mode against the CPU oracle's committed curve (tests/golden/train_curve_yolov5seg_128.npz, written by
    oracle/make_train_curve.py): the oracle reaches a held-out mIoU of 0.82 (val_diceloss.py:37-75 metric, eval-mode BN).
 2. ``test_short_training_run_tracks_the_oracle``: 24 steps at 96x96 against a live CPU-oracle run, per-step losses.  Parity
@@ -131,6 +131,7 @@ def test_training_run_reaches_the_oracle_miou(mode):
     from tests.util import GOLDEN
     fx = np.load(os.path.join(GOLDEN, "train_curve_yolov5seg_128.npz"))
     S_, BS_, STEPS_, LR_, NB_ = (int(fx["hyp"][0]), int(fx["hyp"][1]), int(fx["hyp"][2]), float(fx["hyp"][3]), int(fx["hyp"][4]))
+    LRF_ = float(fx["hyp"][5])
     ref_losses, ref_mious = fx["losses"], fx["mious"]
     assert ref_mious[-1] >= 0.3, "the oracle run must actually learn"
     ydl.set_compute_dtype(mode)
@@ -148,6 +149,8 @@ def test_training_run_reaches_the_oracle_miou(mode):
         losses, mious = [], []
         for st in range(STEPS_):
             x, t = batches[st % NB_]
+            for gparam in opt.param_groups:
+                gparam["lr"] = LR_ * (1.0 - (1.0 - LRF_) * st / STEPS_)
             opt.zero_grad()
             total, items = crit(m(x), t)
             total.backward()
@@ -170,7 +173,7 @@ def test_training_run_reaches_the_oracle_miou(mode):
           f"{np.abs(mious - ref_mious).max():.4f}; loss gap first 10 steps {head.max():.2e}, whole run mean {gap.mean():.2e} max {gap.max():.2e}")
     assert head.max() <= (1e-3 if mode == "f32" else 2e-2), head
     assert gap.mean() <= (5e-3 if mode == "f32" else 1e-2), gap.mean()
-    assert abs(mious[-1] - ref_mious[-1]) <= 0.01 * 3, (mode, mious[-1], ref_mious[-1])
+    assert abs(mious[-1] - ref_mious[-1]) <= 0.01, (mode, mious[-1], ref_mious[-1])
     assert mious[-1] >= 0.3
 
 

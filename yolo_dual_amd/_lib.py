@@ -90,6 +90,8 @@ SIGNATURES = {
     "ydl_group_softmax_fwd": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
     "ydl_group_softmax_bwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i64, _i, _i, _vp]),
     "ydl_cast_f32": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
+    "ydl_reduce_chunks": (_i, [_i, _vp, _vp, _i64, _i, _vp]),
+    "ydl_cast_to_f32": (_i, [_i, _vp, _vp, _i64, _i, _vp]),
 }
 
 _lib = None

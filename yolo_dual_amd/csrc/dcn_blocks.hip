@@ -335,3 +335,42 @@ extern "C" int ydl_cast_f32(int dtype, const float* src, int lds_, void* dst, in
     YDL_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// gradient transport helpers of yolo_dual_amd.parallel (the hand-rolled reduce-scatter + all-gather, bf16 wire format):
+//   ydl_reduce_chunks: dst[i] (f32) = sum_r src[r][i], r = 0..nchunks-1 in that fixed order (src f32 or bf16)
+//   ydl_cast_to_f32  : dst[i] (f32) (+)= src[i] (bf16 / f32)
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(const T* __restrict__ src, float* __restrict__ dst, long long n, int nchunks) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < nchunks; ++r) s += ET<T>::ld(src + (size_t)r * n + i);
+        dst[i] = s;
+    }
+}
+extern "C" int ydl_reduce_chunks(int dtype, const void* src, float* dst, int64_t n, int nchunks, void* stream) {
+    YDL_CHECK((dtype == YDL_F32 || dtype == YDL_BF16) && src && dst && n > 0 && nchunks > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = stream_grid(n);
+    if (dtype == YDL_F32) reduce_chunks_kernel<float><<<grid, 256, 0, st>>>((const float*)src, dst, n, nchunks);
+    else reduce_chunks_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, dst, n, nchunks);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long long n, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = ET<T>::ld(src + i);
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+extern "C" int ydl_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, int accumulate, void* stream) {
+    YDL_CHECK((dtype == YDL_F32 || dtype == YDL_BF16) && src && dst && n > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = stream_grid(n);
+    if (dtype == YDL_F32) cast_to_f32_kernel<float><<<grid, 256, 0, st>>>((const float*)src, dst, n, accumulate);
+    else cast_to_f32_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, dst, n, accumulate);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

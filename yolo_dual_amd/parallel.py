@@ -12,7 +12,15 @@ per-GPU) — this is the new capability modelled on utils/torch_utils.py:55-63. 
   * parameters that get no gradient (dead head layers, ResNet layer4) are known after the first step and are
     excluded: a bucket never waits for them, and their (zero) ranges are not sent;
   * averaging (1/world) is folded into the optimizer kernel's ``grad_scale``.
-BatchNorm stays per-GPU exactly like the reference's DataParallel (its SyncBN branch is dead code)."""
+BatchNorm stays per-GPU exactly like the reference's DataParallel (its SyncBN branch is dead code).
+
+Two knobs exist for the xGMI mesh (no 8-GPU node has run this code yet — there is no scaling curve):
+  * ``algo="rs_ag"``: a hand-rolled reduce-scatter + all-gather in which every rank exchanges 1/world of the bucket with
+    EVERY peer at once (point-to-point sends to all 7 neighbours, so all 7 links carry traffic, where a ring is bound by one
+    link per direction), sums the received pieces locally in a fixed rank order (bitwise reproducible), and sends its reduced
+    piece back to every peer.  The comparator for RCCL's own all-reduce (``algo="allreduce"``, the default).
+  * ``wire="bf16"``: gradients cross the links as bf16 (31 MB instead of 62 MB for BASELINE config 2).  With ``rs_ag`` the
+    local sum stays f32 (one rounding on the way out, one on the way back); with ``allreduce`` RCCL sums in bf16."""
 from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
@@ -24,10 +32,52 @@ from . import config
 from .optim import FlatSGDEMA
 
 
+def _local_ops(t: torch.Tensor):
+    """(cast f32 -> wire, cast wire -> f32 [accumulate], sum of chunks -> f32) for the device the arena lives on: HIP kernels on
+    the GPU; plain tensor ops when the reducer is rehearsed on CPU tensors (gloo tests — collectives plumbing only)"""
+    if t.is_cuda:
+        from . import _lib as L
+        from .tape import _p, _stream
+
+        def to_wire(src, dst):
+            if dst.dtype == torch.float32:
+                L.call("ydl_copy2d", L.YDL_F32, _p(src), src.numel(), _p(dst), src.numel(), 1, src.numel(), 0, _stream())
+            else:
+                L.call("ydl_cast_f32", L.YDL_BF16, _p(src), src.numel(), _p(dst), src.numel(), 1, src.numel(), 0, _stream())
+
+        def from_wire(src, dst):
+            L.call("ydl_cast_to_f32", L.YDL_F32 if src.dtype == torch.float32 else L.YDL_BF16, _p(src), _p(dst), src.numel(), 0, _stream())
+
+        def sum_chunks(src, dst, nchunks):
+            L.call("ydl_reduce_chunks", L.YDL_F32 if src.dtype == torch.float32 else L.YDL_BF16, _p(src), _p(dst), dst.numel(), nchunks,
+                   _stream())
+        return to_wire, from_wire, sum_chunks
+
+    def to_wire(src, dst):
+        dst.copy_(src)
+
+    def from_wire(src, dst):
+        dst.copy_(src)
+
+    def sum_chunks(src, dst, nchunks):
+        acc = torch.zeros_like(dst)
+        for r in range(nchunks):                      # fixed rank order, f32 accumulation
+            acc += src.view(nchunks, -1)[r].float()
+        dst.copy_(acc)
+    return to_wire, from_wire, sum_chunks
+
+
 class GradBucketReducer:
-    def __init__(self, opt: FlatSGDEMA, bucket_bytes: int = 16 << 20, group=None):
+    def __init__(self, opt: FlatSGDEMA, bucket_bytes: int = 16 << 20, group=None, algo: str = "allreduce", wire: str = "f32"):
+        if algo not in ("allreduce", "rs_ag") or wire not in ("f32", "bf16"):
+            raise ValueError("algo must be 'allreduce' or 'rs_ag', wire 'f32' or 'bf16'")
         self.opt = opt
         self.group = group
+        self.algo, self.wire = algo, wire
+        self._wdt = torch.float32 if wire == "f32" else torch.bfloat16
+        self._stage: Dict[int, dict] = {}
+        self._post: List = []
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(bucket_bytes // 4, 1)
         self._plan: Optional[List[dict]] = None
@@ -89,12 +139,71 @@ class GradBucketReducer:
 
     def _launch(self, bi: int) -> None:
         b = self._plan[bi]
-        view = self.opt.grads_arena[b["a"]:b["b"]]
+        self._reduce_range(b["a"], b["b"], key=bi)
+        self._launched.append((b["a"], b["b"]))
+
+    def _reduce_range(self, a: int, b: int, key=None) -> None:
+        """start the sum over ranks of grads_arena[a:b]; completion + write-back happen in ``_drain``"""
+        view = self.opt.grads_arena[a:b]
         if view.is_cuda:        # weight gradients are produced on the side stream (tape.side_stream)
             from .tape import side_stream
             torch.cuda.current_stream().wait_stream(side_stream(view.device))
-        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._launched.append((b["a"], b["b"]))
+        if self.algo == "allreduce" and self.wire == "f32":
+            self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        to_wire, from_wire, sum_chunks = _local_ops(view)
+        n = b - a
+        W = self.world
+        chunk = (n + W - 1) // W
+        st = self._stage.get(key) if key is not None else None
+        if st is None or st["n"] != n:
+            st = {"n": n, "send": torch.zeros(W * chunk, dtype=self._wdt, device=view.device),
+                  "recv": torch.zeros(W * chunk, dtype=self._wdt, device=view.device),
+                  "own": torch.zeros(chunk, dtype=torch.float32, device=view.device)}
+            if key is not None:
+                self._stage[key] = st
+        to_wire(view, st["send"][:n])
+        if self.algo == "allreduce":                       # bf16 wire, RCCL sums in bf16
+            h = dist.all_reduce(st["send"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._post.append(([h], lambda st=st, view=view, n=n: from_wire(st["send"][:n], view)))
+            return
+        # reduce-scatter by hand: piece r of my bucket goes to rank r, pieces from every peer come back — all peers at once
+        me = self.rank
+        ops = []
+        for r in range(W):
+            if r == me:
+                continue
+            ops.append(dist.P2POp(dist.isend, st["send"][r * chunk:(r + 1) * chunk], self._peer(r), self.group))
+            ops.append(dist.P2POp(dist.irecv, st["recv"][r * chunk:(r + 1) * chunk], self._peer(r), self.group))
+        st["recv"][me * chunk:(me + 1) * chunk].copy_(st["send"][me * chunk:(me + 1) * chunk])
+        hs = dist.batch_isend_irecv(ops) if ops else []
+
+        def phase2(st=st, view=view, n=n, chunk=chunk):
+            sum_chunks(st["recv"], st["own"], W)                                   # f32 sum in rank order
+            to_wire(st["own"], st["send"][me * chunk:(me + 1) * chunk])
+            ops2 = []
+            for r in range(W):
+                if r == me:
+                    continue
+                ops2.append(dist.P2POp(dist.isend, st["send"][me * chunk:(me + 1) * chunk], self._peer(r), self.group))
+                ops2.append(dist.P2POp(dist.irecv, st["send"][r * chunk:(r + 1) * chunk], self._peer(r), self.group))
+            for h in (dist.batch_isend_irecv(ops2) if ops2 else []):
+                h.wait()
+            from_wire(st["send"][:n], view)                                        # every rank holds the same reduced bucket
+        self._post.append((hs, phase2))
+
+    def _peer(self, r: int) -> int:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def _drain(self) -> None:
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        for hs, fn in self._post:
+            for h in hs:
+                h.wait()
+            fn()
+        self._post = []
 
     # ------------------------------------------------------------------ end of backward
     def finish(self) -> float:
@@ -118,12 +227,10 @@ class GradBucketReducer:
                     else:
                         todo.append([off, off + n])
             for a, b in todo:
-                self._handles.append(dist.all_reduce(self.opt.grads_arena[a:b], op=dist.ReduceOp.SUM,
-                                                     group=self.group, async_op=True))
+                self._reduce_range(a, b)
             self._build_plan(live)
-        for h in self._handles:
-            h.wait()
-        self._handles = []
+            self._stage = {}
+        self._drain()
         self._launched = []
         return 1.0 / self.world
 
@@ -132,9 +239,10 @@ class DataParallel:
     """Thin training-step helper: ``dp = DataParallel(model, opt)``; per step ``dp.begin(); loss.backward();
     scale = dp.finish(); opt.step(grad_scale=scale)``."""
 
-    def __init__(self, model, opt: FlatSGDEMA, bucket_bytes: int = 16 << 20, group=None, broadcast: bool = True):
+    def __init__(self, model, opt: FlatSGDEMA, bucket_bytes: int = 16 << 20, group=None, broadcast: bool = True,
+                 algo: str = "allreduce", wire: str = "f32"):
         self.model, self.opt = model, opt
-        self.reducer = GradBucketReducer(opt, bucket_bytes, group)
+        self.reducer = GradBucketReducer(opt, bucket_bytes, group, algo=algo, wire=wire)
         if broadcast and dist.is_initialized() and self.reducer.world > 1:
             dist.broadcast(opt.params_arena, src=0, group=group)     # identical replicas (params + BN buffers)
             if opt.ema_arena is not None:
@@ -159,7 +267,6 @@ class DataParallel:
             r._build_plan(live)
         for bi in range(len(r._plan)):
             r._launch(bi)
-        for h in r._handles:
-            h.wait()
-        r._handles, r._launched = [], []
+        r._drain()
+        r._launched = []
         return 1.0 / r.world
