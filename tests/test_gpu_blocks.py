@@ -395,3 +395,46 @@ def test_miou_confusion():
     miou, ious = cm.compute_iou()
     assert abs(miou - float(g.flat["miou"])) < 1e-9
     assert np.allclose(ious, g.flat["ious"], atol=1e-9)
+
+
+def test_two_losses_on_one_replicated_prediction_add_their_gradients():
+    """a second SegmentationLoss on the same model output must not overwrite the first one's side-channel gradient: the sum of
+    two losses gives the gradients of the two separate runs added up; a second backward through a consumed region raises"""
+    import yaml, os
+    import yolo_dual_amd as ydl
+    from oracle.fill import fill_state_dict
+    ydl.set_compute_dtype("f32")
+    try:
+        cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg", "yolov5_seg.yaml")))
+        for sec in ("backbone", "head"):
+            for l in cfg[sec]:
+                l[2] = "C3" if l[2] == "C3_DCN" else l[2]
+        cw = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+        gen = torch.Generator("cuda").manual_seed(0)
+        x = torch.rand(2, 3, 64, 64, device="cuda", generator=gen)
+        t1 = torch.randint(0, 12, (2, 64, 64), device="cuda", generator=gen)
+        t2 = torch.randint(0, 12, (2, 64, 64), device="cuda", generator=gen)
+
+        def run(which):
+            m = ydl.YOLOv5Seg(cfg)
+            m.img_size = [64, 64]
+            sd = m.state_dict()
+            fill_state_dict(sd, 9, bn_stats=False)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            out = m(x)
+            la, _ = ydl.SegmentationLoss(12, 0.0, cw, "dice")(out, t1)
+            lb, _ = ydl.SegmentationLoss(12, 0.0, cw, "jaccard")(out, t2)
+            tot = {"a": la, "b": lb, "ab": la + lb}[which]
+            tot.backward()
+            if which == "ab":
+                with pytest.raises(RuntimeError, match="second backward"):
+                    (la + lb).backward()
+            return {k: p.grad.detach().clone() for k, p in m.named_parameters() if getattr(p, "_ydl_touched", False)}
+        ga, gb, gab = run("a"), run("b"), run("ab")
+        assert sorted(ga) == sorted(gab)
+        for k in gab:
+            want = ga[k] + gb[k]
+            assert l2_err(gab[k].cpu(), want.cpu()) < 2e-4, (k, l2_err(gab[k].cpu(), want.cpu()))
+    finally:
+        ydl.set_compute_dtype("bf16")

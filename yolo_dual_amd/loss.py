@@ -63,7 +63,7 @@ class _SegLossFn(torch.autograd.Function):
             L.call("ydl_seg_loss_rep_bwd", _p(low), sn, sc, sh, sw, _p(target), _p(ctx.cw), ctx.kind, ctx.ls, ctx.eps,
                    N, C, h, w, rh, rw, _p(ws), _p(g), _p(dlow), _stream())
             # the replica-summed gradient travels through the side channel; autograd gets a zero placeholder
-            lazy.dlow = dlow
+            lazy.dlow = dlow if lazy.dlow is None else lazy.dlow + dlow      # (a repeated backward of this loss adds up)
             lazy.dummy = g.new_zeros(1).expand(ctx.shape)
             return lazy.dummy, None, None, None, None, None, None
         pred, target, ws = ctx.saved_tensors
@@ -105,6 +105,13 @@ class SegmentationLoss(nn.Module):
         if lazy is not None and (lazy.version != pred._version or pred.dtype != torch.float32
                                  or not (pred.requires_grad and torch.is_grad_enabled())):
             lazy = None
+        if lazy is not None:
+            # ONE consumer may use the side channel; a second loss on the same prediction takes the dense kernels, whose
+            # gradient autograd adds to the first one's (the region folds the side-channel part into the dense sum)
+            if getattr(lazy, "claimed", False):
+                lazy = None
+            else:
+                lazy.claimed = True
         total, losses = _SegLossFn.apply(pred, target, cw, self.kind, self.label_smoothing, 1e-6, lazy)
         if self.sync:
             return total, losses.tolist()

@@ -71,6 +71,9 @@ class _Region(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         tape: Tape = ctx.tape
+        if tape is None:
+            raise RuntimeError("second backward through a taped region: its activations were released by the first one "
+                               "(retain_graph is not supported; run the forward again)")
         if ctx.out_v is not None:
             tape.seed_grad_nchw(ctx.out_v, gout)
         else:

@@ -138,10 +138,10 @@ class LazyOutput:
     ``low`` = the (N, C, H, W) tensor the (N, C, H*rh, W*rw) output replicates, ``version`` = the output's version
     counter when it was produced (an in-place edit by the caller invalidates the shortcut), ``dlow`` = replica-summed
     gradient handed back by the loss backward, ``dummy`` = the zero-stride placeholder gradient it returned."""
-    __slots__ = ("low", "rep", "version", "dlow", "dummy")
+    __slots__ = ("low", "rep", "version", "dlow", "dummy", "claimed")
 
     def __init__(self, low: torch.Tensor, rep):
-        self.low, self.rep, self.version, self.dlow, self.dummy = low, tuple(rep), -1, None, None
+        self.low, self.rep, self.version, self.dlow, self.dummy, self.claimed = low, tuple(rep), -1, None, None, False
 
 
 class Tape:
