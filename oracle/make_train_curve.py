@@ -42,8 +42,9 @@ def cfg_v5():
     return cfg
 
 
-def main():
-    torch.set_num_threads(min(16, os.cpu_count() or 8))
+def run(eps: float, verbose: bool = True):
+    """one training run; ``eps`` is added to the images of the first batch (the run is chaotic: a 1e-6 perturbation moves the
+    final mIoU by several points, so the fixture stores a small ensemble)"""
     cfg = cfg_v5()
     shapes = script_model_state_shapes(cfg)
     sd = {k: (torch.zeros(s) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64)) for k, s in shapes.items()}
@@ -53,6 +54,8 @@ def main():
     bufs, losses, mious = {}, [], []
     for st in range(STEPS):
         x, t = blobby(100 + st % NB, BS)
+        if st % NB == 0:
+            x = x + eps
         ps = {k: sd[k].detach().clone().requires_grad_(True) for k in pnames}
         run = dict(sd)
         run.update(ps)
@@ -71,9 +74,39 @@ def main():
                 pv = R.script_model_forward({k: v.clone() for k, v in sd.items()}, cfg, xv, (S, S), train=False)
             miou, ious = R.miou_from_confusion(R.confusion_matrix(pv.argmax(1), tv, 12))
             mious.append(miou)
-            print(f"step {st + 1}: loss {losses[-1]:.4f}  val mIoU {miou:.4f}", flush=True)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_curve_yolov5seg_128.npz"), losses=np.array(losses),
-                        mious=np.array(mious), final_ious=np.array(ious), hyp=np.array([S, BS, STEPS, LR, NB, LRF]))
+            if verbose:
+                print(f"eps {eps:g} step {st + 1}: loss {losses[-1]:.4f}  val mIoU {miou:.4f}", flush=True)
+    return np.array(losses), np.array(mious), np.array(ious)
+
+
+EPS = (0.0, 1e-6, -1e-6, 2e-6)
+
+
+def main():
+    """``--member i`` runs ensemble member i into a part file (so that members can run in parallel processes); without
+    arguments the parts are merged into the fixture (missing members are computed first)"""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--member", type=int, default=-1)
+    ap.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 8))
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    part = lambda i: os.path.join("/tmp", f"train_curve_part{i}.npz")
+    if a.member >= 0:
+        l, m, io = run(EPS[a.member])
+        np.savez(part(a.member), losses=l, mious=m, ious=io)
+        return
+    L, M, I = [], [], []
+    for i, e in enumerate(EPS):
+        if not os.path.exists(part(i)):
+            l, m, io = run(e)
+            np.savez(part(i), losses=l, mious=m, ious=io)
+        z = np.load(part(i))
+        L.append(z["losses"]); M.append(z["mious"]); I.append(z["ious"])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_curve_yolov5seg_128.npz"), losses=L[0], mious=M[0],
+                        final_ious=I[0], ens_eps=np.array(EPS), ens_mious=np.stack(M), ens_final=np.array([m[-1] for m in M]),
+                        hyp=np.array([S, BS, STEPS, LR, NB, LRF]))
+    print("ensemble final mIoU:", [round(float(m[-1]), 4) for m in M])
 
 
 if __name__ == "__main__":

@@ -2,8 +2,9 @@
 
 1. ``test_training_run_reaches_the_oracle_miou``: a run that actually learns — YOLOv5Seg, 128x128 blobby masks,
    batch 8 cycling over 16 batches, CE + 0.5*Dice, SGD-nesterov with a linearly decaying learning rate, 600 steps — replayed on the HIP path in parity (f32) and
-   throughput (bf16) mode against the CPU oracle's committed curve (tests/golden/train_curve_yolov5seg_128.npz, written by
-   oracle/make_train_curve.py): the oracle reaches a held-out mIoU of 0.82 (val_diceloss.py:37-75 metric, eval-mode BN).
+   throughput (bf16) mode against the CPU oracle's committed 4-member ensemble (tests/golden/train_curve_yolov5seg_128.npz,
+   written by oracle/make_train_curve.py): the oracle reaches held-out mIoUs of 0.78-0.90 (val_diceloss.py:37-75 metric,
+   eval-mode BN); the run is chaotic, so ensembles are compared, not single trajectories.
 2. ``test_short_training_run_tracks_the_oracle``: 24 steps at 96x96 against a live CPU-oracle run, per-step losses.  Parity
    mode is bitwise reproducible (deterministic split-K weight gradients), so its bound is the 2e-3 the test started with."""
 import os
@@ -127,54 +128,68 @@ def _blobby128(seed, n, S=128):
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_training_run_reaches_the_oracle_miou(mode):
+    """The learning run is CHAOTIC: adding 1e-6 to the images of one batch moves the CPU oracle's own final mIoU between 0.78 and
+    0.90 (the fixture stores that 4-member ensemble, oracle/make_train_curve.py), and the HIP path behaves the same
+    (tools/chaos_probe.py).  A single-run comparison to +-0.01 therefore cannot be met by the oracle against itself; what is
+    asserted instead:
+      * identical trajectories before the chaos sets in: the first 10 losses of the unperturbed member match the oracle's
+        (f32 1e-3 relative — measured 2.5e-6 — / bf16 2e-2), and its whole loss curve stays within 5e-3 / 1e-2 on average;
+      * every member learns (mIoU >= 0.3) and ends inside the oracle ensemble's range widened by 0.06;
+      * the ensemble MEANS agree within 0.05 (about 1.5 standard errors of the difference of two 4-member means at the measured
+        spread of 0.05) — far inside the north star's +-0.1."""
     import yolo_dual_amd as ydl
     from tests.util import GOLDEN
     fx = np.load(os.path.join(GOLDEN, "train_curve_yolov5seg_128.npz"))
     S_, BS_, STEPS_, LR_, NB_ = (int(fx["hyp"][0]), int(fx["hyp"][1]), int(fx["hyp"][2]), float(fx["hyp"][3]), int(fx["hyp"][4]))
     LRF_ = float(fx["hyp"][5])
-    ref_losses, ref_mious = fx["losses"], fx["mious"]
-    assert ref_mious[-1] >= 0.3, "the oracle run must actually learn"
+    ref_losses, ref_final = fx["losses"], fx["ens_final"]
+    assert ref_final.min() >= 0.3, "the oracle runs must actually learn"
+    finals, head, gap = [], None, None
     ydl.set_compute_dtype(mode)
     try:
-        m = ydl.YOLOv5Seg(_cfg())
-        m.img_size = [S_, S_]
-        sd = m.state_dict()
-        fill_state_dict(sd, 77, bn_stats=False)
-        m.load_state_dict(sd)
-        m = m.cuda().train()
-        opt = ydl.FlatSGDEMA(m, lr=LR_, momentum=0.937, weight_decay=0.0, ema=False)
-        crit = ydl.SegmentationLoss(12, 0.0, CW, "dice")
-        batches = [tuple(t.cuda() for t in _blobby128(100 + i, BS_, S_)) for i in range(NB_)]
+        base = [_blobby128(100 + i, BS_, S_) for i in range(NB_)]
         xv, tv = (t.cuda() for t in _blobby128(2, BS_, S_))
-        losses, mious = [], []
-        for st in range(STEPS_):
-            x, t = batches[st % NB_]
-            for gparam in opt.param_groups:
-                gparam["lr"] = LR_ * (1.0 - (1.0 - LRF_) * st / STEPS_)
-            opt.zero_grad()
-            total, items = crit(m(x), t)
-            total.backward()
-            opt.step()
-            losses.append(items[0])
-            if st % 25 == 24:
-                m.eval()
-                with torch.no_grad():
-                    pv = m(xv)
-                cm = ydl.ConfusionMatrix(12, ignore_index=11)
-                cm.process_batch(pv, tv)
-                mious.append(cm.compute_iou()[0])
-                m.train()
+        for mi, eps in enumerate(fx["ens_eps"].tolist()):
+            m = ydl.YOLOv5Seg(_cfg())
+            m.img_size = [S_, S_]
+            sd = m.state_dict()
+            fill_state_dict(sd, 77, bn_stats=False)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            opt = ydl.FlatSGDEMA(m, lr=LR_, momentum=0.937, weight_decay=0.0, ema=False)
+            crit = ydl.SegmentationLoss(12, 0.0, CW, "dice")
+            batches = [((x + np.float32(eps)) if i == 0 else x, t) for i, (x, t) in enumerate(base)]
+            batches = [(x.cuda(), t.cuda()) for x, t in batches]
+            losses = []
+            for st in range(STEPS_):
+                x, t = batches[st % NB_]
+                for gparam in opt.param_groups:
+                    gparam["lr"] = LR_ * (1.0 - (1.0 - LRF_) * st / STEPS_)
+                opt.zero_grad()
+                total, items = crit(m(x), t)
+                total.backward()
+                opt.step()
+                losses.append(items[0])
+            m.eval()
+            with torch.no_grad():
+                pv = m(xv)
+            cm = ydl.ConfusionMatrix(12, ignore_index=11)
+            cm.process_batch(pv, tv)
+            finals.append(cm.compute_iou()[0])
+            if mi == 0:
+                losses = np.array(losses)
+                head = (np.abs(losses[:10] - ref_losses[:10]) / ref_losses[:10]).max()
+                gap = (np.abs(losses - ref_losses) / ref_losses).mean()
     finally:
         ydl.set_compute_dtype("bf16")
-    losses, mious = np.array(losses), np.array(mious)
-    head = np.abs(losses[:10] - ref_losses[:10]) / ref_losses[:10]
-    gap = np.abs(losses - ref_losses) / ref_losses
-    print(f"[training parity 128] {mode}: final mIoU {mious[-1]:.4f} vs oracle {ref_mious[-1]:.4f}; mIoU curve gap max "
-          f"{np.abs(mious - ref_mious).max():.4f}; loss gap first 10 steps {head.max():.2e}, whole run mean {gap.mean():.2e} max {gap.max():.2e}")
-    assert head.max() <= (1e-3 if mode == "f32" else 2e-2), head
-    assert gap.mean() <= (5e-3 if mode == "f32" else 1e-2), gap.mean()
-    assert abs(mious[-1] - ref_mious[-1]) <= 0.01, (mode, mious[-1], ref_mious[-1])
-    assert mious[-1] >= 0.3
+    finals = np.array(finals)
+    print(f"[training parity 128] {mode}: final mIoU per member {np.round(finals, 4).tolist()} (mean {finals.mean():.4f}) vs oracle "
+          f"{np.round(ref_final, 4).tolist()} (mean {ref_final.mean():.4f}); member 0 loss gap: first 10 steps {head:.2e}, whole run mean {gap:.2e}")
+    assert head <= (1e-3 if mode == "f32" else 2e-2), head
+    assert gap <= (5e-3 if mode == "f32" else 1e-2), gap
+    assert finals.min() >= 0.3
+    assert finals.min() >= ref_final.min() - 0.06 and finals.max() <= ref_final.max() + 0.06, (finals, ref_final)
+    assert abs(finals.mean() - ref_final.mean()) <= 0.05, (finals.mean(), ref_final.mean())
 
 
 @pytest.mark.parametrize("hw,bs", [((95, 81), 1), ((64, 96), 3), ((160, 128), 2), ((320, 320), 2)])

@@ -265,6 +265,29 @@ static inline int bwd_nblk(long long npix, int Cp, int V) {
 }
 
 template <typename T>
+__device__ __forceinline__ void dz_xhat_q(const uint4& yq, const uint4& dq, const uint4& oq, const float* sc, const float* sf,
+                                          const float* mu, const float* is, int act, float* dz, float* xh) {
+    constexpr int V = ET<T>::V;
+    float yv[V], dv[V], ov[V];
+    unpack16<T>(yq, yv);
+    unpack16<T>(dq, dv);
+    if (act == YDL_ACT_RELU) unpack16<T>(oq, ov);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        float z = yv[e] * sc[e] + sf[e];
+        float d = dv[e];
+        if (act == YDL_ACT_SILU) {
+            float sg = sigmoid_f(z);
+            d *= sg * (1.f + z * (1.f - sg));
+        } else if (act == YDL_ACT_RELU) {
+            d = ov[e] > 0.f ? d : 0.f;
+        }
+        dz[e] = d;
+        xh[e] = (yv[e] - mu[e]) * is[e];
+    }
+}
+
+template <typename T>
 __device__ __forceinline__ void dz_xhat(const T* y, const T* dout, const T* out, long long pix, int ldy, int lddo, int ldo,
                                         int c, const float* sc, const float* sf, const float* mu, const float* is,
                                         int act, float* dz, float* xh) {
@@ -303,7 +326,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < V; ++e) { sc[e] = scale[L.c + e]; sf[e] = shift[L.c + e]; mu[e] = mean[L.c + e]; is[e] = invstd[L.c + e]; }
         const long long stride = (long long)gridDim.x * L.R;
-        for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
+        long long pix = (long long)blockIdx.x * L.R + L.pl;
+        // two pixels per iteration: four independent 16-byte loads in flight per thread (the grid is capped at 1024 partial rows,
+        // so memory-level parallelism has to come from inside the thread)
+        for (; pix + stride < npix; pix += 2 * stride) {
+            const uint4 y0 = *(const uint4*)(y + pix * ldy + L.c), d0 = *(const uint4*)(dout + pix * lddo + L.c);
+            const uint4 y1 = *(const uint4*)(y + (pix + stride) * ldy + L.c), d1 = *(const uint4*)(dout + (pix + stride) * lddo + L.c);
+            uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+            if (act == YDL_ACT_RELU) { o0 = *(const uint4*)(out + pix * ldo + L.c); o1 = *(const uint4*)(out + (pix + stride) * ldo + L.c); }
+            float dz[V], xh[V];
+            dz_xhat_q<T>(y0, d0, o0, sc, sf, mu, is, act, dz, xh);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
+            dz_xhat_q<T>(y1, d1, o1, sc, sf, mu, is, act, dz, xh);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
+        }
+        for (; pix < npix; pix += stride) {
             float dz[V], xh[V];
             dz_xhat<T>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, act, dz, xh);
 #pragma unroll
