@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many tensor sets (defeats the 256 MB MALL)")
     ap.add_argument("--acc", type=int, default=0, help="dgrad accumulate flag")
     ap.add_argument("--ring", type=int, default=1, help="0: igemm_kernel instead of the LDS-DMA ring kernel (igemm2)")
+    ap.add_argument("--det", action="store_true", help="wgrad: deterministic slab + fixed-order reduce instead of f32 atomics")
     ap.add_argument("--check", action="store_true", help="compare fwd/dgrad of the ring kernel with igemm_kernel (max abs diff)")
     a = ap.parse_args()
     L.debug_set(0, a.wg)
@@ -62,6 +63,7 @@ def main():
         gp = ctypes.byref(g)
         ws = torch.empty(L.lib().ydl_conv_fwd_stats_ws_bytes(gp, dt) // 4, device=dev)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
+        wsd = torch.empty(max(L.lib().ydl_conv_wgrad_ws_bytes(gp, dt) // 4, 4), device=dev) if a.det else None
         flops = 2.0 * N * Ho * Ho * Cout * k * k * Cin
         byts = (N * Hi * Hi * Cin + N * Ho * Ho * Cout) * (2 if a.dtype == "bf16" else 4)
         it = [0]
@@ -71,7 +73,8 @@ def main():
             return it[0] % R
         ops = {"fwd": lambda i: L.call("ydl_conv_fwd", gp, dt, P(xs[i]), P(w), P(ys[i]), None if a.nostats else P(ws), 0, st),
                "dgrad": lambda i: L.call("ydl_conv_dgrad", gp, dt, P(dys[i]), P(wt), P(dxs[i]), a.acc, st),
-               "wgrad": lambda i: L.call("ydl_conv_wgrad", gp, dt, P(xs[i]), P(dys[i]), P(dw), st)}
+               "wgrad": (lambda i: L.call("ydl_conv_wgrad_det", gp, dt, P(xs[i]), P(dys[i]), P(dw), P(wsd), st)) if a.det else
+                        (lambda i: L.call("ydl_conv_wgrad", gp, dt, P(xs[i]), P(dys[i]), P(dw), st))}
         line = f"[{li:2d}] {Cin:5d}->{Cout:5d} k{k}s{s} @{Ho:4d}"
         if a.check:
             outs = []
