@@ -883,9 +883,10 @@ struct PwArgs {
     const void* X; const void* W; void* Y; float* stats;
     int M, lda, ldc, Cout, WN, accumulate, block_m, stats_ld;
     unsigned bytesX, ldw_bytes;
+    int tstore;          // 1: stores go through a per-wave LDS transpose (16 bytes per lane, whole pixel rows per instruction)
 };
 
-template <typename T, int RB, int CT, int NW>
+template <typename T, int RB, int CT, int NW, bool TS>
 __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     constexpr int ES = sizeof(T);
     constexpr int J = RB / 64;                  // fragment groups per K row (each = 4 lane-group chunks of 16 B)
@@ -895,6 +896,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;                                      // [Cout][RB], chunk q of row r at slot q ^ sw(r)
     float* sred = (float*)(smem + (size_t)p.Cout * RB);            // [WP][Cout][2] (mean, M2) + [WP] counts
+    unsigned char* const stage = smem + (((size_t)p.Cout * RB + (size_t)(NW / p.WN) * p.Cout * 2 * sizeof(float) + 64 + 15) & ~(size_t)15);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int WN = p.WN, WP = NW / WN;
     const int wc = wave % WN, wp = wave / WN;
@@ -961,7 +963,45 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
                 }
                 if (i + NB < nsteps) load(i + NB, bq[u]);
                 const int m = m_begin + ((i * WP + wp) << 4) + lrow;
-                if (m < m_end) {
+                if constexpr (TS) {
+                    // The accumulator layout gives a lane 4 consecutive channels of one pixel: a direct store writes a pixel row
+                    // in 8-byte pieces from CT different instructions.  Transposed through a wave-private LDS tile (no barrier: one
+                    // wave's LDS operations complete in order) every lane stores 16 bytes and NCH neighbouring lanes one whole row.
+                    constexpr int NCH = CT * 16 * ES / 16;          // 16-byte chunks per tile row
+                    constexpr int RPP = 64 / NCH;                   // rows per store instruction
+                    unsigned char* tb = stage + wave * (16 * NCH * 16);
+                    const int swm = (NCH - 1) & 15;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        if constexpr (sizeof(T) == 4) {
+                            const int ch = c * 4 + lgrp;
+                            *(float4*)(tb + lrow * (NCH * 16) + ((ch ^ (lrow & swm)) << 4)) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+                        } else {
+                            const int ch = c * 2 + (lgrp >> 1);
+                            uint2 w2;
+                            w2.x = (uint32_t)f2bf(acc[c][0]) | ((uint32_t)f2bf(acc[c][1]) << 16);
+                            w2.y = (uint32_t)f2bf(acc[c][2]) | ((uint32_t)f2bf(acc[c][3]) << 16);
+                            *(uint2*)(tb + lrow * (NCH * 16) + ((ch ^ (lrow & swm)) << 4) + ((lgrp & 1) << 3)) = w2;
+                        }
+                    }
+                    const int tile_m = m_begin + ((i * WP + wp) << 4);
+#pragma unroll
+                    for (int ps = 0; ps < 16 / RPP; ++ps) {
+                        const int row = ps * RPP + lane / NCH, ch = lane % NCH;
+                        const uint4 v4 = *(const uint4*)(tb + row * (NCH * 16) + ((ch ^ (row & swm)) << 4));
+                        if (tile_m + row < m_end) *(uint4*)((unsigned char*)(Yg + (size_t)(tile_m + row) * p.ldc + co0) + (ch << 4)) = v4;
+                    }
+                    if (want_stats && m < m_end) {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                s1[c * 4 + e] += acc[c][e];
+                                s2[c * 4 + e] = fmaf(acc[c][e], acc[c][e], s2[c * 4 + e]);
+                            }
+                        cnt += 1.f;
+                    }
+                } else if (!TS && m < m_end) {
                     T* dst = Yg + (size_t)m * p.ldc + co0 + lgrp * 4;
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
@@ -1067,7 +1107,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     }
 }
 
-struct PwPlan { bool ok; int RB, CT, WN, NW, block_m, grid_m; size_t smem; };
+struct PwPlan { bool ok; int RB, CT, WN, NW, block_m, grid_m; size_t smem, tstage; };
 static int g_pw_enabled = 1;
 static int g_dgrad_merge = 1;
 // eligibility + launch geometry; a pure function of its arguments (the stats-workspace queries call it too)
@@ -1092,20 +1132,27 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
     pl.block_m = bm;
     pl.grid_m = (M + bm - 1) / bm;
     const int WP = pl.NW / pl.WN;
-    pl.smem = (size_t)wbytes + (size_t)WP * Cout * 2 * sizeof(float) + 64;
+    pl.smem = (((size_t)wbytes + (size_t)WP * Cout * 2 * sizeof(float) + 64 + 15) & ~(size_t)15);
+    pl.tstage = (size_t)pl.NW * 16 * (pl.CT * 16 * es);      // per-wave transposed store tiles
     pl.ok = true;
     return pl;
 }
 
 template <typename T, int RB, int CT, int NW>
 static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int fam) {
-    YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW>), 140 * 1024);
+    YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, true>), 160 * 1024);
+    YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, false>), 160 * 1024);
     {
         static const std::string nm = std::string("pw_kernel<") + (sizeof(T) == 4 ? "f32" : "bf16") + "," + std::to_string(RB) + "," +
                                       std::to_string(CT) + "," + std::to_string(NW) + ">";
         ydl_note_kernel(fam, nm.c_str());
     }
-    pw_kernel<T, RB, CT, NW><<<pl.grid_m, NW * 64, pl.smem, st>>>(a);
+    PwArgs a2 = a;
+    static const int no_t = getenv("YDL_PW_NOTSTORE") ? atoi(getenv("YDL_PW_NOTSTORE")) : 0;
+    // (bf16 only: the f32 instantiations lose an occupancy step or spill with the extra staging code; parity mode keeps direct stores)
+    a2.tstore = (sizeof(T) == 2 && !a.accumulate && !no_t && pl.smem + pl.tstage <= 158 * 1024) ? 1 : 0;
+    if (a2.tstore) pw_kernel<T, RB, CT, NW, true><<<pl.grid_m, NW * 64, pl.smem + pl.tstage, st>>>(a2);
+    else pw_kernel<T, RB, CT, NW, false><<<pl.grid_m, NW * 64, pl.smem, st>>>(a2);
     YDL_LAUNCH_CHECK();
     return 0;
 }
