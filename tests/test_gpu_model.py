@@ -121,9 +121,11 @@ def test_resnet50_yaml_trajectory(mode):
     m.img_size = [64, 64]
     # 53 convolutions on a 64x64 input: the deepest BatchNorms normalise over 8 values (2x2 pixels, batch 2), and fp32 itself is
     # only reproducible to 3.4e-4 on the output probabilities here (CPU oracle in f32 vs the same oracle in f64; the f32 oracle
-    # equals the reference fixture bit for bit) — this path lands at 3.2e-4.  Hence 1e-3 on the outputs and 1e-2 on gradient norms
-    # (see test_resnet50seg_trajectory); the loss, an average over all pixels, still holds 1e-4.
-    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode, f32_grad_tol=1e-2, later_loss_tol=1e-3, f32_out_tol=1e-3)
+    # equals the reference fixture bit for bit) — this path lands at 3.2e-4.  Hence 1e-3 on the outputs; the loss, an average over
+    # all pixels, still holds 1e-4.  Gradient norms: the f32 oracle with every weight scaled by (1 + 1e-7) moves the layer1 / layer2
+    # BatchNorm gradient norms of this fixture by up to 1.5e-2 (backbone.1.layer.0.conv2.bn.bias), the f64 oracle by 1.3e-2 — ReLU
+    # masks flip under BatchNorms that see 8..128 values.  The HIP path differs by up to 1.6e-2 on the same entries: bound 3e-2.
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode, f32_grad_tol=3e-2, later_loss_tol=1e-3, f32_out_tol=1e-3)
 
 
 @pytest.mark.parametrize("mode", ["f32"])

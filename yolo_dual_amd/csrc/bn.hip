@@ -206,10 +206,10 @@ static inline dim3 lay_grid(long long npix, int Cp, int V, int max_x) {
 
 // apply: out = act(y*scale + shift) (+res).
 // scale/shift arrays must be readable up to Cp (padded entries = 0 => padded channels stay 0 for SiLU/none).
-template <typename T>
+template <typename T, int ACT, int RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int ldr,
-                                                         int res_mode, int act, T* __restrict__ out, int ldo,
+                                                         T* __restrict__ out, int ldo,
                                                          long long npix, int Cp) {
     constexpr int V = ET<T>::V;
     const Lay L = make_lay<V>(Cp);
@@ -221,13 +221,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
         float v[V], r[V];
         unpack16<T>(*(const uint4*)(y + pix * ldy + L.c), v);
-        if (res_mode != YDL_RES_NONE) unpack16<T>(*(const uint4*)(res + pix * ldr + L.c), r);
+        if (RES != YDL_RES_NONE) unpack16<T>(*(const uint4*)(res + pix * ldr + L.c), r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float z = v[e] * sc[e] + sf[e];
-            if (res_mode == YDL_RES_BEFORE_ACT) z += r[e];
-            float o = act == YDL_ACT_SILU ? silu_f(z) : (act == YDL_ACT_RELU ? fmaxf(z, 0.f) : z);
-            if (res_mode == YDL_RES_AFTER_ACT) o += r[e];
+            if (RES == YDL_RES_BEFORE_ACT) z += r[e];
+            float o = ACT == YDL_ACT_SILU ? silu_f(z) : (ACT == YDL_ACT_RELU ? fmaxf(z, 0.f) : z);
+            if (RES == YDL_RES_AFTER_ACT) o += r[e];
             v[e] = o;
         }
         *(uint4*)(out + pix * ldo + L.c) = pack16<T>(v);
@@ -244,10 +244,25 @@ extern "C" int ydl_bn_act_fwd(int dtype, const void* y, int ldy, const float* sc
     YDL_CHECK(aligned16(y) && aligned16(out) && (res == nullptr || aligned16(res)), "16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid = lay_grid(npix, Cp, V, 256 * 8);
-    if (dtype == YDL_F32)
-        bn_act_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)y, ldy, scale, shift, (const float*)res, ldr, res_mode, act, (float*)out, ldo, npix, Cp);
-    else
-        bn_act_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)y, ldy, scale, shift, (const bf16_t*)res, ldr, res_mode, act, (bf16_t*)out, ldo, npix, Cp);
+    YDL_CHECK(act == YDL_ACT_NONE || act == YDL_ACT_SILU || act == YDL_ACT_RELU, "unknown activation");
+    YDL_CHECK(res_mode == YDL_RES_NONE || res_mode == YDL_RES_BEFORE_ACT || res_mode == YDL_RES_AFTER_ACT, "unknown residual mode");
+    // activation and residual mode are compile-time: a run-time switch inside the unrolled element loop made the compiler emit a
+    // scalar branch per element
+#define YDL_FWD_LAUNCH(T, A, R) bn_act_fwd_kernel<T, A, R><<<grid, 256, 0, st>>>((const T*)y, ldy, scale, shift, (const T*)res, ldr, (T*)out, ldo, npix, Cp)
+#define YDL_FWD_RES(T, A)                                                                  \
+    do {                                                                                   \
+        if (res_mode == YDL_RES_NONE) YDL_FWD_LAUNCH(T, A, YDL_RES_NONE);                  \
+        else if (res_mode == YDL_RES_BEFORE_ACT) YDL_FWD_LAUNCH(T, A, YDL_RES_BEFORE_ACT); \
+        else YDL_FWD_LAUNCH(T, A, YDL_RES_AFTER_ACT);                                      \
+    } while (0)
+#define YDL_FWD_ACT(T)                                                 \
+    do {                                                               \
+        if (act == YDL_ACT_SILU) YDL_FWD_RES(T, YDL_ACT_SILU);         \
+        else if (act == YDL_ACT_RELU) YDL_FWD_RES(T, YDL_ACT_RELU);    \
+        else YDL_FWD_RES(T, YDL_ACT_NONE);                             \
+    } while (0)
+    if (dtype == YDL_F32) YDL_FWD_ACT(float);
+    else YDL_FWD_ACT(bf16_t);
     YDL_LAUNCH_CHECK();
     return 0;
 }
@@ -264,22 +279,22 @@ static inline int bwd_nblk(long long npix, int Cp, int V) {
     return (int)lay_grid(npix, Cp, V, BWD_MAX_PARTIALS).x;
 }
 
-template <typename T>
+template <typename T, int ACT>
 __device__ __forceinline__ void dz_xhat_q(const uint4& yq, const uint4& dq, const uint4& oq, const float* sc, const float* sf,
-                                          const float* mu, const float* is, int act, float* dz, float* xh) {
+                                          const float* mu, const float* is, float* dz, float* xh) {
     constexpr int V = ET<T>::V;
     float yv[V], dv[V], ov[V];
     unpack16<T>(yq, yv);
     unpack16<T>(dq, dv);
-    if (act == YDL_ACT_RELU) unpack16<T>(oq, ov);
+    if (ACT == YDL_ACT_RELU) unpack16<T>(oq, ov);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         float z = yv[e] * sc[e] + sf[e];
         float d = dv[e];
-        if (act == YDL_ACT_SILU) {
+        if (ACT == YDL_ACT_SILU) {
             float sg = sigmoid_f(z);
             d *= sg * (1.f + z * (1.f - sg));
-        } else if (act == YDL_ACT_RELU) {
+        } else if (ACT == YDL_ACT_RELU) {
             d = ov[e] > 0.f ? d : 0.f;
         }
         dz[e] = d;
@@ -287,23 +302,23 @@ __device__ __forceinline__ void dz_xhat_q(const uint4& yq, const uint4& dq, cons
     }
 }
 
-template <typename T>
+template <typename T, int ACT>
 __device__ __forceinline__ void dz_xhat(const T* y, const T* dout, const T* out, long long pix, int ldy, int lddo, int ldo,
                                         int c, const float* sc, const float* sf, const float* mu, const float* is,
-                                        int act, float* dz, float* xh) {
+                                        float* dz, float* xh) {
     constexpr int V = ET<T>::V;
     float yv[V], dv[V], ov[V];
     unpack16<T>(*(const uint4*)(y + pix * ldy + c), yv);
     unpack16<T>(*(const uint4*)(dout + pix * lddo + c), dv);
-    if (act == YDL_ACT_RELU) unpack16<T>(*(const uint4*)(out + pix * ldo + c), ov);
+    if (ACT == YDL_ACT_RELU) unpack16<T>(*(const uint4*)(out + pix * ldo + c), ov);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         float z = yv[e] * sc[e] + sf[e];
         float d = dv[e];
-        if (act == YDL_ACT_SILU) {
+        if (ACT == YDL_ACT_SILU) {
             float sg = sigmoid_f(z);
             d *= sg * (1.f + z * (1.f - sg));
-        } else if (act == YDL_ACT_RELU) {
+        } else if (ACT == YDL_ACT_RELU) {
             d = ov[e] > 0.f ? d : 0.f;
         }
         dz[e] = d;
@@ -311,12 +326,12 @@ __device__ __forceinline__ void dz_xhat(const T* y, const T* dout, const T* out,
     }
 }
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int lddo,
                                                             const T* __restrict__ out, int ldo,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            int act, float* __restrict__ part, long long npix, int Cp) {
+                                                            float* __restrict__ part, long long npix, int Cp) {
     constexpr int V = ET<T>::V;
     const Lay L = make_lay<V>(Cp);
     float sb[V], sg[V], sc[V], sf[V], mu[V], is[V];
@@ -333,18 +348,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             const uint4 y0 = *(const uint4*)(y + pix * ldy + L.c), d0 = *(const uint4*)(dout + pix * lddo + L.c);
             const uint4 y1 = *(const uint4*)(y + (pix + stride) * ldy + L.c), d1 = *(const uint4*)(dout + (pix + stride) * lddo + L.c);
             uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-            if (act == YDL_ACT_RELU) { o0 = *(const uint4*)(out + pix * ldo + L.c); o1 = *(const uint4*)(out + (pix + stride) * ldo + L.c); }
+            if (ACT == YDL_ACT_RELU) { o0 = *(const uint4*)(out + pix * ldo + L.c); o1 = *(const uint4*)(out + (pix + stride) * ldo + L.c); }
             float dz[V], xh[V];
-            dz_xhat_q<T>(y0, d0, o0, sc, sf, mu, is, act, dz, xh);
+            dz_xhat_q<T, ACT>(y0, d0, o0, sc, sf, mu, is, dz, xh);
 #pragma unroll
             for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
-            dz_xhat_q<T>(y1, d1, o1, sc, sf, mu, is, act, dz, xh);
+            dz_xhat_q<T, ACT>(y1, d1, o1, sc, sf, mu, is, dz, xh);
 #pragma unroll
             for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
         }
         for (; pix < npix; pix += stride) {
             float dz[V], xh[V];
-            dz_xhat<T>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, act, dz, xh);
+            dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh);
 #pragma unroll
             for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
         }
@@ -414,12 +429,12 @@ __global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restri
     }
 }
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int lddo,
                                                            const T* __restrict__ out, int ldo,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ sums, int act, T* __restrict__ dy, int lddy,
+                                                           const float* __restrict__ sums, T* __restrict__ dy, int lddy,
                                                            T* __restrict__ dres, int lddr, long long npix, int Cp) {
     constexpr int V = ET<T>::V;
     const Lay L = make_lay<V>(Cp);
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const long long stride = (long long)gridDim.x * L.R;
     for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
         float dz[V], xh[V], o[V];
-        dz_xhat<T>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, act, dz, xh);
+        dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh);
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = sc[e] * (dz[e] - kb[e] - xh[e] * kg[e]);
         *(uint4*)(dy + pix * lddy + L.c) = pack16<T>(o);
@@ -464,15 +479,23 @@ extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dou
     float* part = ws;
     float* sums = ws + (size_t)BWD_MAX_PARTIALS * 2 * Cp;
     dim3 g3 = lay_grid(npix, Cp, V, 256 * 8);
-    if (dtype == YDL_F32) {
-        bn_bwd_reduce_kernel<float><<<g1, 256, 0, st>>>((const float*)y, ldy, (const float*)dout, lddo, (const float*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp);
-        bn_bwd_merge_kernel<<<(Cp + 7) / 8, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
-        bn_bwd_apply_kernel<float><<<g3, 256, 0, st>>>((const float*)y, ldy, (const float*)dout, lddo, (const float*)out, ldo, scale, shift, mean, invstd, sums, act, (float*)dy, lddy, (float*)dres, lddr, npix, Cp);
-    } else {
-        bn_bwd_reduce_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, lddo, (const bf16_t*)out, ldo, scale, shift, mean, invstd, act, part, npix, Cp);
-        bn_bwd_merge_kernel<<<(Cp + 7) / 8, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);
-        bn_bwd_apply_kernel<bf16_t><<<g3, 256, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, lddo, (const bf16_t*)out, ldo, scale, shift, mean, invstd, sums, act, (bf16_t*)dy, lddy, (bf16_t*)dres, lddr, npix, Cp);
-    }
+    YDL_CHECK(act == YDL_ACT_NONE || act == YDL_ACT_SILU || act == YDL_ACT_RELU, "unknown activation");
+#define YDL_BWD_LAUNCH(T, A)                                                                                                          \
+    do {                                                                                                                              \
+        bn_bwd_reduce_kernel<T, A><<<g1, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale, shift,     \
+                                                       mean, invstd, part, npix, Cp);                                                \
+        bn_bwd_merge_kernel<<<(Cp + 7) / 8, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);            \
+        bn_bwd_apply_kernel<T, A><<<g3, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale, shift,      \
+                                                      mean, invstd, sums, (T*)dy, lddy, (T*)dres, lddr, npix, Cp);                   \
+    } while (0)
+#define YDL_BWD_ACT(T)                                                                                                                \
+    do {                                                                                                                              \
+        if (act == YDL_ACT_SILU) YDL_BWD_LAUNCH(T, YDL_ACT_SILU);                                                                     \
+        else if (act == YDL_ACT_RELU) YDL_BWD_LAUNCH(T, YDL_ACT_RELU);                                                                \
+        else YDL_BWD_LAUNCH(T, YDL_ACT_NONE);                                                                                         \
+    } while (0)
+    if (dtype == YDL_F32) YDL_BWD_ACT(float);
+    else YDL_BWD_ACT(bf16_t);
     YDL_LAUNCH_CHECK();
     return 0;
 }

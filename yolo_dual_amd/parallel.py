@@ -80,6 +80,10 @@ class GradBucketReducer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(bucket_bytes // 4, 1)
+        # RCCL's send/recv are ordered on the stream.  The gloo transport (rehearsals of the N>1 path on one GPU or on the CPU) takes
+        # the raw pointer of a device tensor and copies from the host side with no stream ordering at all: there the stream has to
+        # be drained before a point-to-point batch is posted
+        self._host_p2p = dist.is_initialized() and dist.get_backend(group) == "gloo"
         self._plan: Optional[List[dict]] = None
         self._slot_of: Dict[int, int] = {id(p): i for i, (p, *_r) in enumerate(opt._slots)}
         self._handles: List = []
@@ -176,6 +180,8 @@ class GradBucketReducer:
             ops.append(dist.P2POp(dist.isend, st["send"][r * chunk:(r + 1) * chunk], self._peer(r), self.group))
             ops.append(dist.P2POp(dist.irecv, st["recv"][r * chunk:(r + 1) * chunk], self._peer(r), self.group))
         st["recv"][me * chunk:(me + 1) * chunk].copy_(st["send"][me * chunk:(me + 1) * chunk])
+        if self._host_p2p and view.is_cuda:
+            torch.cuda.current_stream().synchronize()
         hs = dist.batch_isend_irecv(ops) if ops else []
 
         def phase2(st=st, view=view, n=n, chunk=chunk):
@@ -187,6 +193,8 @@ class GradBucketReducer:
                     continue
                 ops2.append(dist.P2POp(dist.isend, st["send"][me * chunk:(me + 1) * chunk], self._peer(r), self.group))
                 ops2.append(dist.P2POp(dist.irecv, st["send"][r * chunk:(r + 1) * chunk], self._peer(r), self.group))
+            if self._host_p2p and view.is_cuda:
+                torch.cuda.current_stream().synchronize()
             for h in (dist.batch_isend_irecv(ops2) if ops2 else []):
                 h.wait()
             from_wire(st["send"][:n], view)                                        # every rank holds the same reduced bucket
