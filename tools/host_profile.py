@@ -25,15 +25,37 @@ def step():
     opt.step()
 
 
+# the backward closures run on autograd's device thread: profile Tape.run_backward there with a second profiler
+from yolo_dual_amd import tape as _tape
+pr_b = cProfile.Profile()
+_orig_rb = _tape.Tape.run_backward
+def _rb(self):
+    if PROFILE_BW[0]:
+        pr_b.enable()
+    try:
+        return _orig_rb(self)
+    finally:
+        if PROFILE_BW[0]:
+            pr_b.disable()
+PROFILE_BW = [False]
+_tape.Tape.run_backward = _rb
+
 for _ in range(3):
     step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
+PROFILE_BW[0] = True
 pr.enable()
 for _ in range(10):
     step()
 pr.disable()
+PROFILE_BW[0] = False
 torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
 print(s.getvalue()[:6000])
+
+s = io.StringIO()
+pstats.Stats(pr_b, stream=s).sort_stats("tottime").print_stats(24)
+print("---- backward closures (autograd thread) ----")
+print(s.getvalue()[:5000])

@@ -47,6 +47,15 @@ def overlap_wgrad() -> bool:
     return _STATE["overlap_wgrad"]
 
 
+def wgrad_batch() -> int:
+    """weight-gradient launches per fork of the side stream (tape._defer_wgrad)"""
+    return _STATE.setdefault("wgrad_batch", max(int(os.environ.get("YDL_WGRAD_BATCH", "8")), 1))
+
+
+def set_wgrad_batch(n: int) -> None:
+    _STATE["wgrad_batch"] = max(int(n), 1)
+
+
 def set_overlap_wgrad(on: bool) -> None:
     _STATE["overlap_wgrad"] = bool(on)
 

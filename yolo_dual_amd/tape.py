@@ -156,6 +156,8 @@ class Tape:
         self.touched_params: List[torch.nn.Parameter] = []
         self._side_used = False
         self._keep: List[Var] = []
+        self._pending_wgrad: List[Callable] = []   # weight-gradient launches waiting for the next fork of the side stream
+        self._bw_left = 0
         self.ext = None      # (Var, tensor) of a region whose external output was written directly (softmax head)
 
     # ------------------------------------------------------------------ buffers
@@ -271,10 +273,35 @@ class Tape:
         L.call("ydl_nhwc_to_nchw", v.dt, _p(self._gbuf(v)), v.ld, _p(out), v.N, v.C, v.H, v.W, 0, _stream())
         return out
 
+    def _defer_wgrad(self, launch: Callable, keep=()) -> None:
+        """queue a weight-gradient launch for the side stream.  One fork (event record + stream wait) per ``wgrad_batch`` launches
+        instead of one per layer: forks cost host time in eager mode and a cross-branch edge each in a captured graph.  The last
+        layers of the sweep fork at once, so the tail of the backward pass does not wait for a batch to fill."""
+        from . import config as _cfg
+        self._pending_wgrad.append(launch)
+        self._keep.extend(keep)
+        if len(self._pending_wgrad) >= _cfg.wgrad_batch() or self._bw_left <= 2:
+            self._flush_wgrads()
+
+    def _flush_wgrads(self) -> None:
+        if not self._pending_wgrad:
+            return
+        side = side_stream(self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = _stream()
+            for launch in self._pending_wgrad:
+                launch(st)
+        self._pending_wgrad.clear()
+        self._side_used = True
+
     def run_backward(self) -> None:
-        for fn in reversed(self.bw):
+        n = len(self.bw)
+        for i, fn in enumerate(reversed(self.bw)):
+            self._bw_left = n - 1 - i
             fn()
         self.bw.clear()
+        self._flush_wgrads()
         if self._side_used:
             torch.cuda.current_stream().wait_stream(side_stream(self.device))   # parameter grads complete
             self._side_used = False
@@ -460,15 +487,10 @@ class Tape:
                 self._bw_split(m, subs, dy, wt, Cout_p, Ho, Wo, st2)
                 return
             if x.need and _cfg.overlap_wgrad():
-                side = side_stream(self.device)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    m.wgrad(self, gp, x, dy, _stream())
                 # dy was allocated on the main stream and would die with this closure while the side stream still reads
                 # it: park the reference until the streams are joined at the end of run_backward (graph-capture safe,
                 # unlike Tensor.record_stream)
-                self._keep.append(dy)
-                self._side_used = True
+                self._defer_wgrad(lambda sst: m.wgrad(self, gp, x, dy, sst), keep=(dy, geom))
             else:
                 m.wgrad(self, gp, x, dy, st2)
             if x.need:
@@ -515,14 +537,10 @@ class Tape:
             jobs.append((v, c0_, gv, d))
         overlap = _cfg.overlap_wgrad() and any(v.need for (v, _c, _g, _d) in jobs)
         if overlap:
-            side = side_stream(self.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            def launch(sst, jobs=jobs):
                 for i, (v, c0_, gv, d) in enumerate(jobs):
-                    m.wgrad(self, ctypes.byref(gv), v, d, _stream(), col0=c0_, final=(i == len(jobs) - 1))
-            self._keep.extend(d for (_v, _c, _g, d) in jobs)
-            self._keep.append(dy)
-            self._side_used = True
+                    m.wgrad(self, ctypes.byref(gv), v, d, sst, col0=c0_, final=(i == len(jobs) - 1))
+            self._defer_wgrad(launch, keep=[d for (_v, _c, _g, d) in jobs] + [dy])
         else:
             for i, (v, c0_, gv, d) in enumerate(jobs):
                 m.wgrad(self, ctypes.byref(gv), v, d, st2, col0=c0_, final=(i == len(jobs) - 1))
