@@ -269,6 +269,23 @@ int ydl_cast_f32(int dtype, const float* src, int lds, void* dst, int ldd, int64
 int ydl_reduce_chunks(int dtype, const void* src, float* dst, int64_t n, int nchunks, void* stream);
 int ydl_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, int accumulate, void* stream);
 
+/* ---- GPU half of the per-sample input preparation -------------------------------------------------------
+ * JSONSegmentDataset._resize_and_pad + the format conversion of __getitem__ (unet-lite/yolo5-seg/seg_diceloss_yolov5.py:
+ * 309-349): img.resize((new_w,new_h), Image.BILINEAR) pasted on a (128,128,128) canvas, /255, HWC -> CHW float32.
+ * src: uint8 [h][w][3] on the device; dst: float [3][S][S]; tmp: uint8 [h][new_w][3] scratch (may be NULL when new_w == w).
+ * The arithmetic is Pillow's ImagingResample for 8-bit images (horizontal pass, 8-bit intermediate, vertical pass; 22-bit
+ * fixed-point coefficients): the tables are built on the host in double exactly like Pillow's precompute_coeffs /
+ * normalize_coeffs_8bpc (yolo_dual_amd/data.py) — bounds int [out][2] = (first source index, tap count), coef int
+ * [out][ksize].  The kernels trust the tables (first + count <= source size).  fill = canvas grey level (128). */
+int ydl_letterbox_image(const void* src, int h, int w, void* tmp, float* dst, int S, int new_w, int new_h,
+                        int pad_left, int pad_top, const int* xbounds, const int* xcoef, int xksize,
+                        const int* ybounds, const int* ycoef, int yksize, int fill, void* stream);
+/* mask.resize((new_w,new_h), Image.NEAREST) pasted on a 0 canvas, np.clip(., 0, clip_max) (:303), int64 (:315).
+ * src: uint8 [h][w]; dst: int64 [S][S]; xtab int[new_w] / ytab int[new_h]: Pillow's ImagingScaleAffine source indices
+ * (sequential double additions, built on the host). */
+int ydl_letterbox_mask(const void* src, int h, int w, int64_t* dst, int S, int new_w, int new_h, int pad_left,
+                       int pad_top, const int* xtab, const int* ytab, int clip_max, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

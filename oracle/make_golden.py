@@ -419,8 +419,32 @@ def gen_optim():
          hyp=np.array([0.01, 0.937, 5e-4]), steps=np.array(3))
 
 
+def gen_letterbox():
+    """per-sample input preparation: the reference's own `_resize_and_pad` method (unet-lite/yolo5-seg/
+    seg_diceloss_yolov5.py:320-349, exec'd inside a shim class) on Pillow images, then the conversion of __getitem__ (:315-316)"""
+    from PIL import Image
+    path = os.path.join(REF, "unet-lite/yolo5-seg/seg_diceloss_yolov5.py")
+    lines = open(path, encoding="utf-8").read().split("\n")
+    ns = dict(Image=Image, np=np, torch=torch)
+    exec(compile("class _DS:\n" + "\n".join(lines[320 - 1:349]), path, "exec"), ns)
+    for i, (w, h, S) in enumerate([(100, 37, 64), (37, 100, 64), (50, 50, 96), (333, 517, 128), (129, 96, 128), (96, 96, 96)]):
+        rs = np.random.RandomState(700 + i)
+        img = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        mask = rs.randint(0, 16, size=(h, w)).astype(np.uint8)            # labels above 11 exercise the clip of :303
+        ds = ns["_DS"]()
+        ds.img_size = S
+        mclip = np.clip(mask.astype(np.int64), 0, 11)
+        pi, pm = ds._resize_and_pad(Image.fromarray(img).convert("RGB"), Image.fromarray(mclip.astype(np.uint8)))
+        out_i = torch.from_numpy(np.array(pi)).permute(2, 0, 1).float() / 255.0
+        out_m = torch.from_numpy(np.array(pm)).long()
+        save(f"letterbox_{w}x{h}_{S}", img=img, mask=mask, out_img=out_i, out_mask=out_m, meta=np.array([w, h, S, 12]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if "--letterbox" in sys.argv:
+        gen_letterbox()
+        sys.exit(0)
     if "--models-more" in sys.argv:
         gen_models_more()
         sys.exit(0)
@@ -444,3 +468,4 @@ if __name__ == "__main__":
     gen_models(ns5, ns18)
     gen_models_more()
     gen_resnet50_yaml()
+    gen_letterbox()

@@ -33,6 +33,16 @@ def test_train_cli_saves_loads_and_resumes(tmp_path):
     ydl.set_compute_dtype("bf16")
 
 
+def test_train_cli_with_gpu_letterbox(tmp_path):
+    """--raw-size: uint8 samples of another size go through LetterboxGPU (the dataset's _resize_and_pad + /255) into the loop"""
+    import train_seg
+    import yolo_dual_amd as ydl
+    fit = train_seg.train(train_seg.parse_opt(["--arch", "resnet18", "--batch-size", "4", "--imgsz", "64", "--steps-per-epoch", "4",
+                                               "--epochs", "1", "--save-dir", str(tmp_path / "lb"), "--raw-size", "100x72", "--nosave"]))
+    assert 0.0 <= fit <= 1.0
+    ydl.set_compute_dtype("bf16")
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_fused_inference_matches_eval_mode(mode):
     import yaml

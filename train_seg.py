@@ -53,6 +53,8 @@ def parse_opt(argv=None):
     p.add_argument("--lrf", type=float, default=0.2)
     p.add_argument("--momentum", type=float, default=0.937)
     p.add_argument("--weight-decay", type=float, default=0.0005)
+    p.add_argument("--raw-size", type=str, default="", help="WxH: synthetic samples are generated as uint8 arrays of this size and go "
+                   "through the GPU letterbox (yolo_dual_amd.data.LetterboxGPU = the dataset's _resize_and_pad + /255)")
     return p.parse_args(argv)
 
 
@@ -71,9 +73,17 @@ def class_weights(spec: str, nc: int):
     return torch.tensor(vals, dtype=torch.float32)
 
 
-def blobby_batch(gen, n: int, size: int, nc: int, device, palette):
-    """8x8 random class grid nearest-upsampled to size x size; the image is a class colour plus noise"""
+def blobby_batch(gen, n: int, size: int, nc: int, device, palette, letterbox=None, raw=None):
+    """8x8 random class grid nearest-upsampled to size x size; the image is a class colour plus noise.
+    With ``letterbox`` the samples are made as uint8 HWC arrays of the raw size and prepared like the reference's dataset does."""
     import torch
+    if letterbox is not None:
+        rw, rh = raw
+        grid = torch.randint(0, nc - 1, (n, 8, 8), device=device, generator=gen)
+        tgt = grid.repeat_interleave((rh + 7) // 8, 1).repeat_interleave((rw + 7) // 8, 2)[:, :rh, :rw]
+        img = palette[tgt] * 0.8 + 0.2 * torch.rand(n, rh, rw, 3, device=device, generator=gen)
+        u8 = (img * 255).to(torch.uint8)
+        return letterbox.batch([u8[i] for i in range(n)], [tgt[i].to(torch.uint8) for i in range(n)])
     grid = torch.randint(0, nc - 1, (n, 8, 8), device=device, generator=gen)
     rep = (size + 7) // 8
     tgt = grid.repeat_interleave(rep, 1).repeat_interleave(rep, 2)[:, :size, :size].contiguous()
@@ -147,7 +157,11 @@ def train(opt) -> float:
     gen = torch.Generator(device=device).manual_seed(1000 + opt.seed)
     palette = torch.rand(nc, 3, device=device, generator=torch.Generator(device=device).manual_seed(7))
     val_gen = torch.Generator(device=device).manual_seed(99)
-    val_batches = [blobby_batch(val_gen, bs, opt.imgsz, nc, device, palette) for _ in range(2)]
+    lb, raw = None, None
+    if opt.raw_size:
+        raw = tuple(int(v) for v in opt.raw_size.lower().split("x"))
+        lb = ydl.LetterboxGPU(opt.imgsz, num_classes=nc, device=device)
+    val_batches = [blobby_batch(val_gen, bs, opt.imgsz, nc, device, palette, lb, raw) for _ in range(2)]
 
     t0 = time.time()
     for epoch in range(start_epoch, epochs):
@@ -155,7 +169,7 @@ def train(opt) -> float:
         mloss = torch.zeros(3)
         optimizer.zero_grad()
         for i in range(opt.steps_per_epoch):
-            imgs, targets = blobby_batch(gen, bs, opt.imgsz, nc, device, palette)
+            imgs, targets = blobby_batch(gen, bs, opt.imgsz, nc, device, palette, lb, raw)
             pred = model(imgs)                                                          # :1084-1092
             loss, loss_items = criterion(pred, targets)
             loss.backward()

@@ -7,6 +7,7 @@ from . import config
 from .config import compute_dtype, set_compute_dtype
 from .checkpoint import (fuse_conv_and_bn, intersect_dicts, load_checkpoint, load_weights, save_checkpoint, smart_resume,
                          strip_optimizer)
+from .data import LetterboxGPU, letterbox_geometry
 from .evaluate import ConfusionMatrix
 from .loss import JaccardSegmentationLoss, SegmentationLoss
 from .models import (ResNet18, ResNet18Seg, ResNet50, ResNet50Seg, ResNet50SegYaml, SegYoloModel, YOLOv5Seg, YOLOv8Seg,

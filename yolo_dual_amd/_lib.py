@@ -92,6 +92,8 @@ SIGNATURES = {
     "ydl_cast_f32": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
     "ydl_reduce_chunks": (_i, [_i, _vp, _vp, _i64, _i, _vp]),
     "ydl_cast_to_f32": (_i, [_i, _vp, _vp, _i64, _i, _vp]),
+    "ydl_letterbox_image": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "ydl_letterbox_mask": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libydl_hip.so")
-SOURCES = ["err.cpp", "igemm.hip", "bn.hip", "spatial.hip", "loss.hip", "optim.hip", "dcnv3.hip", "dcn_blocks.hip"]
+SOURCES = ["err.cpp", "igemm.hip", "bn.hip", "spatial.hip", "loss.hip", "optim.hip", "dcnv3.hip", "dcn_blocks.hip", "input.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
