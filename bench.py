@@ -305,7 +305,8 @@ def main():
                 tj = json.load(open(tpath))
                 ig = [k for k in tj["kernels"] if "igemm" in k["kernel"] or "pw_kernel" in k["kernel"]]
                 n_l = sum(k["launches_per_step"] for k in ig)
-                traffic = {"unit": "MB per launch (conv fwd+dgrad launches: igemm_kernel + pw_kernel, PMC, FETCH_SIZE x2 per the gfx950 note)",
+                traffic = {"unit": "MB per launch (conv fwd+dgrad launches: igemm / igemm2 / pw kernels; rocprofv3 --pmc FETCH_SIZE x2 per the "
+                                   "gfx950 note + WRITE_SIZE, " + os.path.basename(tpath) + ")",
                            "value": sum(k["fetch_MB"] + k["write_MB"] for k in ig) / max(n_l, 1)}
             except Exception:
                 traffic = None
@@ -315,6 +316,9 @@ def main():
             roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": traffic, "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
                     "share_of_gpu_time": f["ms"] / tot_ms}
+            if traffic is not None:         # the same launches' algorithmic bytes (x, y, w once), for comparison with the PMC figure
+                cf = [fam[k] for k in ("ydl_conv_fwd", "ydl_conv_dgrad") if k in fam]
+                traffic["algorithmic_MB_per_launch"] = sum(c["bytes"] for c in cf) / max(sum(c["n"] for c in cf), 1) / 1e6
         else:
             # HBM-bound family: algorithmic bytes (every input read once, every output written once) over its time
             ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f.get("bytes") else None

@@ -163,6 +163,10 @@ def profile_end():
         flops, nbytes = 0.0, 0.0
         if isinstance(g, ConvGeom):
             flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.k * g.k * g.Cin
+            # algorithmic bytes: input, output and weights once (the weight gradient is f32)
+            es = getattr(g, "_es", 2)
+            wb = float(g.Cout) * g.k * g.k * g.Cin
+            nbytes = (float(g.N) * g.Hi * g.Wi * g.Cin + float(g.N) * g.Ho * g.Wo * g.Cout) * es + wb * (4 if "wgrad" in name else es)
         elif isinstance(g, float):
             nbytes, g = g, None
         d = {"name": name, "ms": e0.elapsed_time(e1), "flops": flops, "bytes": nbytes}
@@ -195,6 +199,7 @@ def call(name: str, *args):
     if name in ("ydl_conv_fwd", "ydl_conv_dgrad", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
         src = args[0]._obj
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
+        g._es = 4 if args[1] == YDL_F32 else 2
     elif name == "ydl_bn_act_fwd":          # algorithmic bytes: y (+ residual) read once, out written once
         es = 4 if args[0] == YDL_F32 else 2
         g = float(args[11]) * args[12] * es * (2 + (1 if args[7] else 0))

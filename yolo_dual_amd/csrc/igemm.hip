@@ -1240,8 +1240,8 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64};
 static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
     switch (id) {
         case 1: return launch_igemm2<256, 128, 8, 4, 3>(a, st, fam);
@@ -1254,6 +1254,9 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         case 8: return launch_igemm2<128, 64, 4, 2, 3>(a, st, fam);       // 72 KB: two CTAs per CU, 64x32 wave tiles
         case 9: return launch_igemm2<64, 128, 4, 2, 3>(a, st, fam);       // 72 KB: two CTAs per CU, 32x64 wave tiles (small M)
         case 10: return launch_igemm2<64, 128, 4, 2, 4>(a, st, fam);      // 96 KB: one CTA per CU, deeper ring
+        case 11: return launch_igemm2<128, 64, 4, 2, 2>(a, st, fam);      // 48 KB: three CTAs per CU (64-channel outputs)
+        case 12: return launch_igemm2<128, 64, 4, 4, 2>(a, st, fam);      // 48 KB, 32x64 wave tiles
+        case 13: return launch_igemm2<128, 64, 8, 4, 2>(a, st, fam);      // 48 KB, 8 waves of 32x32
     }
     ydl_set_error("internal: unknown ring kernel id");
     return 1;
@@ -1263,7 +1266,11 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
 static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int Kc = 0, int taps = 0) {
     TileCfg c;
     c.ring = 0;
-    if (bf16 && g_ring_enabled && Cst >= 128 && Cst % 8 == 0 && nchunks >= 16 && Kc > 0 && Kc % 64 == 0 && taps <= 29) {
+    // 64..127 stored output channels: 128x64 tile, 8 waves, 2 stages = 48 KB (three CTAs per CU).  Measured against the register-staged
+    // kernel: 64->128 k3s2 dgrad @320^2 231 -> 199 us, 64->64 k3 @160^2 78/72 -> 77/60 us, 128->64 k3 @160^2 fwd 120 -> 106 us
+    // (YDL_RING64=0 switches it off, another id selects that instantiation)
+    static const int ring64 = getenv("YDL_RING64") ? atoi(getenv("YDL_RING64")) : 13;
+    if (bf16 && g_ring_enabled && Cst >= (ring64 ? 64 : 128) && Cst % 8 == 0 && nchunks >= 16 && Kc > 0 && Kc % 64 == 0 && taps <= 29) {
         // bf16 MFMA-bound layers (>= 2 K-steps of 64, >= 128 output channels): LDS-DMA ring kernel.  Measured on MI355X over the
         // 3x3 and wide 1x1 layers of BASELINE config 2 (tools/conv_bench.py, forward and dgrad): the 128x128 tile with a 2-stage
         // ring (64 KB of LDS, two CTAs per CU: one CTA's epilogue and load latency hide behind the other's MFMAs) beats the
@@ -1271,6 +1278,7 @@ static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int 
         static const int forced = getenv("YDL_RING") ? atoi(getenv("YDL_RING")) : -1;      // tuning: force an instantiation id
         const long b128 = (long)((M + 127) / 128) * ((Cst + 127) / 128);
         int id = b128 < 256 ? 9 : 7;
+        if (Cst < 128) id = ring64;
         if (forced >= 0) id = forced;
         if (id > 0) { c.ring = id; c.BM = kRingBM[id]; c.BN = kRingBN[id]; return c; }
     }
