@@ -206,4 +206,14 @@ def call(name: str, *args):
     elif name == "ydl_bn_act_bwd":          # y and dout read once, dy written once (the two-phase kernel reads them twice)
         es = 4 if args[0] == YDL_F32 else 2
         g = float(args[22]) * args[24] * es * 3
+    elif name in ("ydl_dcnv3_fwd", "ydl_dcnv3_bwd"):
+        # algorithmic bytes: input, offsets, masks (and grad_output) read once; output / the three f32 gradients written once
+        es = 4 if args[0] == YDL_F32 else 2
+        o = 0 if name == "ydl_dcnv3_fwd" else 3
+        kh, kw, G, Gc = args[5 + o], args[6 + o], args[13 + o], args[14 + o]
+        N, H, W, Ho, Wo = args[16 + o:21 + o]
+        C, pts = G * Gc, G * kh * kw * 3
+        g = float(es) * (N * H * W * C + N * Ho * Wo * (C + pts))
+        if o:
+            g += 4.0 * (N * H * W * C + N * Ho * Wo * pts)
     _PROFILE.append((name, e0, e1, g))
