@@ -92,20 +92,21 @@ TILED = [
     ("k3s2_128_256_f32", "f32", 4, 128, 256, 3, 2, 160, 160, ("igemm_kernel<f32,128,64,4", "igemm_kernel<f32,128,128,8", "wgrad_kernel<f32>", "")),
     # small-M deep layer: 64-pixel / 64-channel tiles
     ("k1_1024_20_f32", "f32", 16, 1024, 1024, 1, 1, 20, 20, ("igemm_kernel<f32,128,64,4", "igemm_kernel<f32,128,64,4", "wgrad_kernel<f32>", "")),
-    # bf16: the throughput-mode instantiations of the same tiles
+    # bf16: the throughput-mode instantiations of the same tiles (3x3 layers below 200 k pixels: the 128-wide weight-gradient kernel
+    # sized to one wave of CTAs; 1x1 layers: the 64x64-tile kernel)
     # (>= 128 output channels and Cin % 64 == 0: the LDS-DMA ring kernel igemm2; otherwise igemm_kernel)
-    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad2_kernel<128>", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
-    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
-    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad2_kernel<64>", "")),
+    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "wgrad2_kernel<128>", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
-    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2_kernel<128,64,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
-    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2_kernel<128,64,8,4,2>", "wgrad2_kernel<64>", "")),
+    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad2_kernel<128>", "")),
     # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
-    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad2_kernel<128>", "")),
     ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
     # ragged: 150 output channels (two channel tiles, the second one partial), odd image size, pixel tail
-    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad2_kernel<128>", "")),
 ]
 
 

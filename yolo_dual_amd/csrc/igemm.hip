@@ -1876,13 +1876,33 @@ static WgradPlan wgrad_plan(const ydl_conv_geom* g, int dtype) {
     // measured on MI355X: the 128-wide pipelined kernel wins on the large-M layers (>= 160x160 at bs 16), the small
     // 64x64-tile kernel (8 CTAs/CU) wins where M is small and the grid of big tiles would be latency-bound
     static const int wg2_min_m = getenv("YDL_WG2_MINM") ? atoi(getenv("YDL_WG2_MINM")) : 200000;
-    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && M >= wg2_min_m) {
+    // mid-size layers (M below the threshold): the 128-wide kernel sized to exactly ONE wave of CTAs (2 per CU x 256 CUs): its
+    // time is very sensitive to the CTA count (atomic volume grows with it, and a second partial wave costs a full tile time) —
+    // 128->256 k3s2 @80^2: 270 CTAs 154 us, 396 CTAs 117 us, 522 CTAs 154 us; the 64x64-tile kernel 148 us
+    // (3x3 layers only: 256->512 k3s2 @40^2 124 -> 93 us, 256->256 k3 @40^2 67 -> 63 us; the 1x1 layers lose 5-18 us with it.
+    //  YDL_WG2_ONEWAVE=0 off, 2 = every layer)
+    static const int onewave = getenv("YDL_WG2_ONEWAVE") ? atoi(getenv("YDL_WG2_ONEWAVE")) : 1;
+    bool mid = false;
+    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && M < wg2_min_m && onewave && Kc % 8 == 0) {
+        const int TCO = g->Cout > 64 ? 128 : 64;
+        const long tiles = (long)((ntaps * Kc + 127) / 128) * ((g->Cout + TCO - 1) / TCO);
+        const long sp = 512 / tiles;
+        mid = sp >= 1 && tiles * sp >= 410 && (M + 63) / 64 >= 4 * sp && (ntaps > 1 || onewave == 2);
+    }
+    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && (M >= wg2_min_m || mid)) {
         const int TCO = g->Cout > 64 ? 128 : 64;
         pl.kind = TCO == 128 ? 4 : 3;
         pl.jtiles = (ntaps * Kc + 127) / 128;
         pl.ctiles = (g->Cout + TCO - 1) / TCO;
         const long tiles = (long)pl.jtiles * pl.ctiles;
         const int stages = (M + 63) / 64;
+        if (mid) {
+            int splits = (int)(512 / tiles);
+            const int per = (stages + splits - 1) / splits;
+            pl.chunk = per * 64;
+            pl.splits = (M + pl.chunk - 1) / pl.chunk;
+            return pl;
+        }
         // Split-K CTA count.  Every CTA ends with one atomic pass over its 128 x TCO f32 tile, and device-scope f32 atomics
         // sustain only ~1.3 TB/s chip-wide (measured), so the atomic volume T * tile_bytes is budgeted at ~20-30 % of the
         // layer's streaming/MFMA time: short 1x1 layers get 256 CTAs, long 3x3 layers up to 2048 (measured optimum per layer
