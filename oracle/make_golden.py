@@ -357,6 +357,28 @@ def gen_dcnv3():
          meta=np.array([K, K, 2, 2, 1, 1, 2, 2, M, D]), offset_scale=np.array(1.0))
 
 
+def gen_dcnv3_tile():
+    """a larger, odd-sized case (2 groups of 128 channels, 19 x 13, O(1) inputs): offsets mostly within 1.5 pixels, 5 % of them up to
+    9 pixels away (many samples leave the image), random upstream gradient"""
+    nsf = load_ref("models/ops_dcnv3/build/lib.linux-x86_64-cpython-38/functions/dcnv3_func.py", [(92, 189)], extra=dict(DCNv3=None))
+    core = nsf["dcnv3_core_pytorch"]
+    rs = np.random.RandomState(397)
+    N, M, H, W, D, K = 2, 2, 19, 13, 128, 3
+    P = K * K
+    inp = torch.from_numpy(rs.randn(N, H, W, M * D).astype(np.float32)).requires_grad_(True)
+    o = (rs.rand(N, H, W, M * P * 2).astype(np.float32) - 0.5) * 3.0
+    far = rs.rand(*o.shape) < 0.05
+    o[far] *= 6.0
+    off = torch.from_numpy(o).requires_grad_(True)
+    mk = rs.rand(N, H, W, M, P).astype(np.float32) + 1e-3
+    msk = torch.from_numpy((mk / mk.sum(-1, keepdims=True)).reshape(N, H, W, M * P)).requires_grad_(True)
+    out = core(inp, off, msk, K, K, 1, 1, 1, 1, 1, 1, M, D, 1.0)
+    gup = rs_tensor(396, out.shape)
+    (out * gup).sum().backward()
+    save("dcnv3_D128_19x13", inp=inp, off=off, msk=msk, out=out, gup=gup, ginp=inp.grad, goff=off.grad, gmsk=msk.grad,
+         meta=np.array([K, K, 1, 1, 1, 1, 1, 1, M, D]), offset_scale=np.array(1.0))
+
+
 def gen_dcnv3_module():
     """the DCNv3 *module* and its YOLO wiring, from the reference's own classes (modules/dcnv3.py:27-136 with the module's
     relative import replaced by a shim whose ``apply`` is the reference's pure-PyTorch core; "common and yolo.py":2-38)"""
@@ -451,8 +473,12 @@ if __name__ == "__main__":
     if "--r50yaml" in sys.argv:
         gen_resnet50_yaml()
         sys.exit(0)
+    if "--dcnv3-tile" in sys.argv:
+        gen_dcnv3_tile()
+        sys.exit(0)
     if "--dcnv3" in sys.argv:
         gen_dcnv3()
+        gen_dcnv3_tile()
         gen_dcnv3_module()
         sys.exit(0)
     ns5 = gen_blocks_v5()
@@ -462,6 +488,7 @@ if __name__ == "__main__":
     gen_blocks_v9()
     ns18, ns50 = gen_resnet()
     gen_dcnv3()
+    gen_dcnv3_tile()
     gen_dcnv3_module()
     gen_miou()
     gen_optim()

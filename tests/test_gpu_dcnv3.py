@@ -18,12 +18,13 @@ def test_dcnv3_forward_backward(name):
     out = dcnv3_core(inp, off, msk, kh, kw, sh, sw, ph, pw, dh, dw, G, D, float(g.flat["offset_scale"]))
     ref = g.t("out")
     assert out.shape == ref.shape
-    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5), float((out.cpu() - ref).abs().max())
+    # absolute floors relative to the fixture's magnitude (the tiled-backward fixture has O(1) inputs, the test.py ones O(0.01))
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=max(1e-5, 1e-5 * float(ref.abs().max()))), float((out.cpu() - ref).abs().max())
     gup = g.t("gup").cuda() if g.has("gup") else torch.ones_like(out)
     (out * gup).sum().backward()
     for t, k in ((inp, "ginp"), (off, "goff"), (msk, "gmsk")):
         r = g.t(k)
-        assert torch.allclose(t.grad.cpu(), r, rtol=1e-3, atol=1e-5), (k, float((t.grad.cpu() - r).abs().max()))
+        assert torch.allclose(t.grad.cpu(), r, rtol=1e-3, atol=max(1e-5, 2e-5 * float(r.abs().max()))), (k, float((t.grad.cpu() - r).abs().max()))
 
 
 def test_dcnv3_bf16_runs_close():
@@ -128,3 +129,4 @@ def test_c3_dcnv3(name, mode):
                 assert rel_err(after[kk].cpu(), v) < 1e-4, kk
     finally:
         ydl.set_compute_dtype("bf16")
+

@@ -192,10 +192,12 @@ def test_dcnv3(name):
     out = R.dcnv3_core(inp, off, msk, kh, kw, sh, sw, ph, pw, dh, dw, G, D, float(g.flat["offset_scale"]))
     ref = g.t("out")
     # models/ops_dcnv3/test.py:85 float tolerance: rtol=1e-2, atol=1e-3; the restatement does much better
-    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-6), float((out - ref).abs().max())
+    # (absolute floor relative to the fixture's magnitude: the tile fixture has O(1) inputs, the test.py ones O(0.01))
+    assert torch.allclose(out, ref, rtol=1e-4, atol=max(1e-6, 1e-5 * float(ref.abs().max()))), float((out - ref).abs().max())
     (out * (g.t("gup") if g.has("gup") else torch.ones_like(out))).sum().backward()
     for t, k in ((inp, "ginp"), (off, "goff"), (msk, "gmsk")):
-        assert torch.allclose(t.grad, g.t(k), rtol=1e-3, atol=1e-5), (k, float((t.grad - g.t(k)).abs().max()))
+        r = g.t(k)
+        assert torch.allclose(t.grad, r, rtol=1e-3, atol=max(1e-5, 1e-5 * float(r.abs().max()))), (k, float((t.grad - r).abs().max()))
 
 
 def test_miou():

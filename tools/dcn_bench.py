@@ -10,12 +10,13 @@ from yolo_dual_amd import _lib as L
 dev = torch.device("cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
+OSTD = float(os.environ.get("DCN_OFF_STD", "2.0"))        # std of the sampling offsets in pixels (trained models: well below 1)
 for (N, H, G, Gc) in [(16, 80, 4, 64), (16, 160, 1, 64), (16, 80, 1, 128), (16, 40, 1, 256), (16, 20, 1, 256)]:
     C, K = G * Gc, 3
     for dt, tdt, es in ((L.YDL_BF16, torch.bfloat16, 2), (L.YDL_F32, torch.float32, 4)):
         R = 3
         xs = [torch.randn(N, H, H, C, device=dev).to(tdt) for _ in range(R)]
-        off = (torch.randn(N, H, H, G * K * K * 2, device=dev) * 2).to(tdt)
+        off = (torch.randn(N, H, H, G * K * K * 2, device=dev) * OSTD).to(tdt)
         msk = torch.softmax(torch.randn(N, H, H, G, K * K, device=dev), -1).reshape(N, H, H, G * K * K).to(tdt)
         out = torch.empty(N, H, H, C, device=dev, dtype=tdt)
         go = torch.randn(N, H, H, C, device=dev).to(tdt)
