@@ -62,6 +62,9 @@ def _worker(rank, world, port, use_graph, q, algo="allreduce", wire="f32"):
 
         if use_graph:
             g = GraphedTrainStep(m, crit, opt, x, t, dp=dp, warmup=2)
+            # more than one rank: the forward/backward graph is cut at every bucket-launch point, the collectives of a replay
+            # overlap with the remaining segments
+            assert g.segmented and len(g._segments) == len(g._bucket_after) + 1 and len(g._segments) >= 3, len(g._segments)
             for _ in range(2):
                 items = g.step()
         else:

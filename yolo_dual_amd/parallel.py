@@ -91,6 +91,7 @@ class GradBucketReducer:
         self._live: Optional[List[bool]] = None
         self._launched: List[Tuple[int, int]] = []
         self.enabled = True          # switched off while a HIP graph of the step is being captured
+        self.capture_cb = None       # segmented graph capture: called with the bucket index instead of launching the collective
         config.add_grad_hook(self._on_grad)
 
     def close(self) -> None:
@@ -139,7 +140,10 @@ class GradBucketReducer:
             return
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
-            self._launch(bi)
+            if self.capture_cb is not None:
+                self.capture_cb(bi)          # the step is being captured: the graph is cut here, the bucket goes out at replay
+            else:
+                self._launch(bi)
 
     def _launch(self, bi: int) -> None:
         b = self._plan[bi]
