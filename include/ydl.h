@@ -35,7 +35,8 @@ extern "C" {
 enum { YDL_F32 = 0, YDL_BF16 = 1, YDL_F16 = 2 /* DCNv3 op only */ };
 enum { YDL_ACT_NONE = 0, YDL_ACT_SILU = 1, YDL_ACT_RELU = 2 };
 /* residual handling of the fused BN/activation kernels */
-enum { YDL_RES_NONE = 0, YDL_RES_AFTER_ACT = 1 /* C3/C2f: act(bn(y)) + r */, YDL_RES_BEFORE_ACT = 2 /* ResNet: act(bn(y) + r) */ };
+enum { YDL_RES_NONE = 0, YDL_RES_AFTER_ACT = 1 /* C3/C2f: act(bn(y)) + r */, YDL_RES_BEFORE_ACT = 2 /* ResNet: act(bn(y) + r) */,
+       YDL_RES_GRAD_ACCUMULATE = 16 /* ydl_bn_act_bwd only, or-ed into res_mode: dres += instead of dres = */ };
 enum { YDL_LOSS_DICE = 0, YDL_LOSS_JACCARD = 1 };
 
 const char* ydl_last_error(void);
@@ -116,8 +117,9 @@ int ydl_bn_act_fwd(int dtype, const void* y, int ldy, const float* scale, const 
                    int64_t npix, int Cp, void* stream);
 int64_t ydl_bn_bwd_ws_bytes(int64_t npix, int Cp);
 /* Backward of out = act(bn(y)) [+res].  dout: grad wrt out.  out: saved output (needed only for RELU).
- * Writes dy (grad wrt conv output), dgamma/dbeta (f32, accumulate flag), and for YDL_RES_BEFORE_ACT the
- * masked gradient dres (may be NULL otherwise; for RES_AFTER_ACT the residual gradient is dout itself). */
+ * Writes dy (grad wrt conv output), dgamma/dbeta (f32, accumulate flag) and, when dres is not NULL, the gradient of the residual
+ * branch in the same pass: the masked gradient dz for YDL_RES_BEFORE_ACT, dout itself for YDL_RES_AFTER_ACT; res_mode may carry
+ * YDL_RES_GRAD_ACCUMULATE (dres already holds another consumer's gradient: add to it). */
 int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
                    const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
                    int res_mode, int act, void* dy, int lddy, void* dres, int lddr,

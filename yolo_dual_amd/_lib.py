@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("YDL_LIB", os.path.join(_HERE, "lib", "libydl_hip.so")
 YDL_F32, YDL_BF16, YDL_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
+RES_GRAD_ACCUMULATE = 16
 LOSS_DICE, LOSS_JACCARD = 0, 1
 RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BILINEAR_AC = 0, 1, 2
 

@@ -305,9 +305,9 @@ __device__ __forceinline__ void dz_xhat_q(const uint4& yq, const uint4& dq, cons
 template <typename T, int ACT>
 __device__ __forceinline__ void dz_xhat(const T* y, const T* dout, const T* out, long long pix, int ldy, int lddo, int ldo,
                                         int c, const float* sc, const float* sf, const float* mu, const float* is,
-                                        float* dz, float* xh) {
+                                        float* dz, float* xh, float* dv) {
     constexpr int V = ET<T>::V;
-    float yv[V], dv[V], ov[V];
+    float yv[V], ov[V];
     unpack16<T>(*(const uint4*)(y + pix * ldy + c), yv);
     unpack16<T>(*(const uint4*)(dout + pix * lddo + c), dv);
     if (ACT == YDL_ACT_RELU) unpack16<T>(*(const uint4*)(out + pix * ldo + c), ov);
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
         }
         for (; pix < npix; pix += stride) {
-            float dz[V], xh[V];
-            dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh);
+            float dz[V], xh[V], dvr[V];
+            dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh, dvr);
 #pragma unroll
             for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
         }
@@ -429,13 +429,14 @@ __global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restri
     }
 }
 
-template <typename T, int ACT>
+// RESM: 0 no residual gradient, 1 dres (+)= dout (residual added after the activation), 2 dres (+)= dz (added before it)
+template <typename T, int ACT, int RESM>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int lddo,
                                                            const T* __restrict__ out, int ldo,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ sums, T* __restrict__ dy, int lddy,
-                                                           T* __restrict__ dres, int lddr, long long npix, int Cp) {
+                                                           T* __restrict__ dres, int lddr, int dres_acc, long long npix, int Cp) {
     constexpr int V = ET<T>::V;
     const Lay L = make_lay<V>(Cp);
     if (!L.live) return;
@@ -448,12 +449,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     const long long stride = (long long)gridDim.x * L.R;
     for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
-        float dz[V], xh[V], o[V];
-        dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh);
+        float dz[V], xh[V], o[V], dv[V];
+        dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh, dv);
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = sc[e] * (dz[e] - kb[e] - xh[e] * kg[e]);
         *(uint4*)(dy + pix * lddy + L.c) = pack16<T>(o);
-        if (dres != nullptr) *(uint4*)(dres + pix * lddr + L.c) = pack16<T>(dz);
+        if (RESM != 0) {                                  // the residual branch's gradient in the same pass (no separate copy kernel)
+            T* rp = dres + pix * lddr + L.c;
+            float r[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) r[e] = RESM == 1 ? dv[e] : dz[e];
+            if (dres_acc) {
+                float old[V];
+                unpack16<T>(*(const uint4*)rp, old);
+#pragma unroll
+                for (int e = 0; e < V; ++e) r[e] += old[e];
+            }
+            *(uint4*)rp = pack16<T>(r);
+        }
     }
 }
 
@@ -467,7 +480,12 @@ extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dou
                               int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
                               float* dgamma, float* dbeta, int accumulate_param_grads,
                               float* ws, int64_t npix, int C, int Cp, void* stream) {
-    (void)gamma; (void)res_mode;
+    (void)gamma;
+    const int dres_acc = (res_mode & YDL_RES_GRAD_ACCUMULATE) ? 1 : 0;
+    const int rmode = res_mode & 15;
+    YDL_CHECK(rmode == YDL_RES_NONE || rmode == YDL_RES_AFTER_ACT || rmode == YDL_RES_BEFORE_ACT, "unknown residual mode");
+    const int resm = dres == nullptr ? 0 : (rmode == YDL_RES_AFTER_ACT ? 1 : 2);     // dres without a mode: the masked gradient
+    YDL_CHECK(dres == nullptr || (lddr >= Cp && aligned16(dres)), "dres must be 16-byte aligned with a stride covering Cp");
     const int V = dtype == YDL_F32 ? 4 : 8;
     YDL_CHECK(y && dout && dy && mean && invstd && scale && shift && ws, "null pointer");
     YDL_CHECK(act != YDL_ACT_RELU || out != nullptr, "RELU backward needs the saved output");
@@ -485,8 +503,15 @@ extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dou
         bn_bwd_reduce_kernel<T, A><<<g1, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale, shift,     \
                                                        mean, invstd, part, npix, Cp);                                                \
         bn_bwd_merge_kernel<<<(Cp + 7) / 8, 256, 0, st>>>(part, nblk, Cp, C, sums, dgamma, dbeta, accumulate_param_grads);            \
-        bn_bwd_apply_kernel<T, A><<<g3, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale, shift,      \
-                                                      mean, invstd, sums, (T*)dy, lddy, (T*)dres, lddr, npix, Cp);                   \
+        if (resm == 0)                                                                                                                \
+            bn_bwd_apply_kernel<T, A, 0><<<g3, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale,      \
+                                                             shift, mean, invstd, sums, (T*)dy, lddy, (T*)dres, lddr, dres_acc, npix, Cp); \
+        else if (resm == 1)                                                                                                           \
+            bn_bwd_apply_kernel<T, A, 1><<<g3, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale,      \
+                                                             shift, mean, invstd, sums, (T*)dy, lddy, (T*)dres, lddr, dres_acc, npix, Cp); \
+        else                                                                                                                          \
+            bn_bwd_apply_kernel<T, A, 2><<<g3, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale,      \
+                                                             shift, mean, invstd, sums, (T*)dy, lddy, (T*)dres, lddr, dres_acc, npix, Cp); \
     } while (0)
 #define YDL_BWD_ACT(T)                                                                                                                \
     do {                                                                                                                              \

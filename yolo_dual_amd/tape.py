@@ -459,26 +459,20 @@ class Tape:
                     dyv.zero_()
                     continue
                 dout = self._gbuf(o)
-                dres_t, dres_ld, tmp_dres = None, 0, None
-                if res is not None and res.need and res_mode == L.RES_BEFORE_ACT:
-                    if res.is_set():
-                        tmp_dres = self.new_like(res)
-                        dres_t, dres_ld = tmp_dres.t, tmp_dres.ld
-                    else:
-                        gbuf, _ = self.grad_target(res)
-                        dres_t, dres_ld = gbuf, res.ld
+                # gradient of the residual branch, written (or added) by the same kernel pass: dz for a residual joined before the
+                # activation, dout itself for one joined after it
+                dres_t, dres_ld, rmode = None, 0, res_mode
+                if res is not None and res.need and res_mode in (L.RES_BEFORE_ACT, L.RES_AFTER_ACT):
+                    gbuf, racc = self.grad_target(res)
+                    dres_t, dres_ld = gbuf, res.ld
+                    if racc:
+                        rmode = res_mode | L.RES_GRAD_ACCUMULATE
                 nws = L.lib().ydl_bn_bwd_ws_bytes(npix, cp) // 4
                 ws2 = torch.empty(nws, dtype=torch.float32, device=self.device)
                 L.call("ydl_bn_act_bwd", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld, _p(dout), o.ld,
                        _p(o.t), o.ld, _p(m.bn.weight[co:]), _p(cf["mean"][co:]), _p(cf["invstd"][co:]),
-                       _p(cf["scale"][co:]), _p(cf["shift"][co:]), res_mode, act, _p(dyv), dy.ld, _p(dres_t), dres_ld,
+                       _p(cf["scale"][co:]), _p(cf["shift"][co:]), rmode, act, _p(dyv), dy.ld, _p(dres_t), dres_ld,
                        _p(gw[co:]), _p(gb[co:]), accw, _p(ws2), npix, cw, cp, st2)
-                if tmp_dres is not None:
-                    gbuf, acc = self.grad_target(res)
-                    L.call("ydl_copy2d", self.dt, _p(tmp_dres.t), tmp_dres.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
-                if res is not None and res.need and res_mode == L.RES_AFTER_ACT:
-                    gbuf, acc = self.grad_target(res)
-                    L.call("ydl_copy2d", self.dt, _p(dout), o.ld, _p(gbuf), res.ld, res.npix, res.C, acc, st2)
             m.touch_bn()          # dgamma / dbeta kernels are enqueued: the DP hook may now reduce their bucket
             # weight gradient (f32, KRSC) accumulated into the parameter's grad storage; on the side stream when the
             # input gradient is needed too, so wgrad and dgrad of a layer overlap
