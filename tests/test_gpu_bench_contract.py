@@ -1,0 +1,33 @@
+"""bench.py's output contract on a small instance of the default workload: exactly one JSON line on stdout with the fields the driver
+reads, a roofline object measured inside the run and a CPU baseline timed beside it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--bs", "2", "--size", "128",
+                        "--cpu-steps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[k], typ), (k, d[k])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-6 * d["value"]            # images/s = bs / step time
+    assert d["launch_mode"] in ("eager", "hipgraph")
+    roof = d["roofline"]
+    assert roof["bound"] in ("mfma", "hbm") and roof["unit"] in ("TFLOP/s", "GB/s") and roof["peak"] > 0
+    assert roof["achieved"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["launches"] > 0 and roof["avg_launch_ms"] > 0 and sum(roof["by_kernel_ms_per_step"].values()) > 0
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == d["unit"] and cpu["sample"]
