@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="keep wgrad on the main stream")
-    ap.add_argument("--eager", action="store_true", help="do not capture the step into HIP graphs")
+    ap.add_argument("--eager", action="store_true", help="issue every launch from Python (no launch-list replay, no HIP graph)")
+    ap.add_argument("--try-hipgraph", action="store_true", help="also time the single-stream HIP-graph capture of the step")
     ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the side stream (wgrad / dead branch) into the graphs too")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -199,14 +200,14 @@ def main():
         return (time.perf_counter() - t) / n * 1e3
 
     if not args.eager:
-        # Launch-mode selection (outside the timed region).  Two ways to issue the same kernels:
-        #   eager   : ~700 launches/step from Python on two HIP streams (wgrad + dead head branch overlap the main chain);
-        #             fastest when the host keeps up (about 7-8 ms of host time per step on an idle CPU)
-        #   hipgraph: the whole step captured into two HIP graphs on one stream; ~0.1 ms of host time per step
-        # Both are measured for a few steps and the faster one runs the timed region; a refused capture falls back to eager.
-        # With several ranks the choice must be the SAME everywhere (eager ranks all-reduce per bucket from the launch
-        # hooks, graphed ranks all-reduce after the replay): timings are max-reduced and a failed capture on any rank
-        # sends every rank to eager.
+        # Launch-mode selection (outside the timed region).  Three ways to issue the same kernels:
+        #   eager   : ~330 entry-point calls per step from Python on two HIP streams (weight gradients + dead head branch overlap the
+        #             main chain); 6-7 ms of host time per step on an idle CPU
+        #   replay  : the same calls, streams and event edges recorded once and re-issued from C with one call per step
+        #             (yolo_dual_amd/replay.py): eager's overlap at about a millisecond of host time
+        #   hipgraph: (--try-hipgraph) the step captured into HIP graphs on one stream: no host time, no overlap
+        # Each is measured for a few steps and the fastest runs the timed region; a failed recording / capture falls back to eager.
+        # With several ranks the choice must be the SAME everywhere: timings are max-reduced, a failure on any rank disables the mode.
         def agree(vals):
             if world == 1:
                 return vals
@@ -214,33 +215,52 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return [float(v) for v in tt.tolist()]
 
+        BIG = 1e9
         t_eager = quick_ms(step)
-        gstep, t_graph, failed = None, float("inf"), 0.0
+        rstep, t_replay, failed = None, BIG, 0.0
         try:
-            from yolo_dual_amd.graph import GraphedTrainStep
-            ydl.config.set_overlap_wgrad(bool(args.graph_overlap) and not args.no_overlap)
-            gstep = GraphedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=2)
+            from yolo_dual_amd.replay import ReplayedTrainStep
+            rstep = ReplayedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=1)
         except Exception as e:          # pragma: no cover
             failed = 1.0
-            print(f"[bench] graph capture unavailable on rank {rank}: {e!r}", file=sys.stderr)
+            print(f"[bench] launch-list recording unavailable on rank {rank}: {e!r}", file=sys.stderr)
             torch.cuda.synchronize()
-        failed = agree([failed])[0]
-        if not failed:
-            t_graph = quick_ms(gstep.step)
-        t_eager, t_graph = agree([t_eager, t_graph if t_graph != float("inf") else 1e9])
-        if not failed and t_graph < t_eager:
-            eager_step, step, mode = step, gstep.step, "hipgraph"
-        else:
-            ydl.config.set_overlap_wgrad(not args.no_overlap)
-            # drop the captured graphs and their private memory pool, then re-warm the eager path: its first steps after a
-            # capture re-grow the caching allocator's per-stream pools (hundreds of ms of hipMalloc on the big workloads)
+        if not agree([failed])[0]:
+            t_replay = quick_ms(rstep.step)
+        gstep, t_graph = None, BIG
+        if args.try_hipgraph:
+            failed = 0.0
+            try:
+                from yolo_dual_amd.graph import GraphedTrainStep
+                ydl.config.set_overlap_wgrad(bool(args.graph_overlap) and not args.no_overlap)
+                gstep = GraphedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=2)
+            except Exception as e:          # pragma: no cover
+                failed = 1.0
+                print(f"[bench] graph capture unavailable on rank {rank}: {e!r}", file=sys.stderr)
+                torch.cuda.synchronize()
+            finally:
+                ydl.config.set_overlap_wgrad(not args.no_overlap)
+            if not agree([failed])[0]:
+                t_graph = quick_ms(gstep.step)
+        t_eager, t_replay, t_graph = agree([t_eager, t_replay, t_graph])
+        best = min(t_eager, t_replay, t_graph)
+        if best == t_replay and t_replay < BIG:
+            eager_step, step, mode = step, rstep.step, "replay"
             gstep = None
+        elif best == t_graph and t_graph < BIG:
+            eager_step, step, mode = step, gstep.step, "hipgraph"
+            rstep = None
+        else:
+            # drop the recorded list / captured graphs and their private memory pools, then re-warm the eager path: its first steps
+            # after that re-grow the caching allocator's per-stream pools (hundreds of ms of hipMalloc on the big workloads)
+            gstep = rstep = None
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
             for _ in range(3):
                 step()
         if rank == 0:
-            print(f"[bench] eager {t_eager:.2f} ms/step, hipgraph {t_graph:.2f} ms/step -> {mode}", file=sys.stderr)
+            fmt = lambda v: "n/a" if v >= BIG else f"{v:.2f}"
+            print(f"[bench] ms/step: eager {fmt(t_eager)}, replay {fmt(t_replay)}, hipgraph {fmt(t_graph)} -> {mode}", file=sys.stderr)
 
     def fence():
         torch.cuda.synchronize()

@@ -288,6 +288,36 @@ int ydl_letterbox_image(const void* src, int h, int w, void* tmp, float* dst, in
 int ydl_letterbox_mask(const void* src, int h, int w, int64_t* dst, int S, int new_w, int new_h, int pad_left,
                        int pad_top, const int* xtab, const int* ytab, int clip_max, void* stream);
 
+/* ---- zero fills (the taped region issues no ATen kernel: buffers that need defined contents are cleared through these) ----
+ * ydl_fill_zero: `bytes` bytes at dst (hipMemsetAsync);  ydl_zero2d: dst[p][0:C] = 0 for npix rows of pixel stride ldd */
+int ydl_fill_zero(void* dst, int64_t bytes, void* stream);
+int ydl_zero2d(int dtype, void* dst, int ldd, int64_t npix, int C, void* stream);
+
+/* ---- launch-list replay: the training step without its host wall -------------------------------------------------------
+ * The reference's hot loop (seg_diceloss_yolov5.py:1084-1103) issues the same sequence of device work every step.  The host
+ * side records ONE step — every entry-point call above with its arguments, the stream it went to, and the cross-stream
+ * event edges — into a ydl_replay and re-issues it with one call per step: no Python, no ctypes marshalling per launch, the
+ * same kernels on the same streams with the same dependencies as the eager step (so the eager step's overlap survives).
+ * Preconditions (the caller's job, yolo_dual_amd/replay.py): every buffer a recorded call names must stay valid and at the same
+ * address for the life of the ydl_replay (a private allocator pool), and every device operation of the step must be in the
+ * list.  Streams are named by slot: the table passed to ydl_replay_run maps slot -> hipStream_t. */
+typedef struct ydl_replay ydl_replay;
+ydl_replay* ydl_replay_create(void);
+void ydl_replay_destroy(ydl_replay* r);
+/* number / names of the recordable entry points (index = `fn` below); generated from this header (tools/gen_replay.py) */
+int ydl_replay_fn_count(void);
+const char* ydl_replay_fn_name(int fn);
+/* append one call: args = the entry point's parameters before `stream`, one 8-byte slot each (integers and pointers as
+ * int64, floats as the bits of a double; a ydl_conv_geom* slot holds a HOST pointer whose struct is copied) */
+int ydl_replay_add_call(ydl_replay* r, int fn, const int64_t* args, int nargs, int stream_slot);
+/* cross-stream edge: hipEventRecord(event[id], stream[slot]) / hipStreamWaitEvent(stream[slot], event[id]) */
+int ydl_replay_add_event_record(ydl_replay* r, int event_id, int stream_slot);
+int ydl_replay_add_event_wait(ydl_replay* r, int event_id, int stream_slot);
+int ydl_replay_size(const ydl_replay* r);
+/* re-issue operations [first, last) in order; h_streams: host array of nstreams hipStream_t.  Stops at the first failing call
+ * (its status is returned, ydl_last_error() says which operation). */
+int ydl_replay_run(ydl_replay* r, int first, int last, void* const* h_streams, int nstreams);
+
 #ifdef __cplusplus
 }
 #endif

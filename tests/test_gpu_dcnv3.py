@@ -7,6 +7,7 @@ import torch
 from tests.util import Golden, names
 
 pytestmark = pytest.mark.gpu
+BF16_GRAD_TOL = 0.2        # relative L2 of a bf16 gradient against the f32 fixture (measured: see the assertion messages)
 
 
 @pytest.mark.parametrize("name", names("dcnv3_"))
@@ -84,6 +85,13 @@ def test_dcnv3_module(name, mode):
             assert l2_err(out.detach().cpu(), g.t("out")) < 6e-2
             (out * g.t("gup").cuda()).sum().backward()
             assert l2_err(x.grad.cpu(), g.t("gx0")) < 0.2
+            grads = g.group("grad") if any(k_.startswith("grad/") for k_ in g.flat) else {}
+            gscale = max([float(v.abs().max()) for v in grads.values()] + [0.0])
+            named = dict(m.named_parameters())
+            errs = {kk: l2_err(named[kk].grad.detach().float().cpu(), v) for kk, v in grads.items()
+                    if float(v.abs().max()) >= 1e-4 * gscale}
+            bad = {k_: round(e, 4) for k_, e in errs.items() if not e < BF16_GRAD_TOL}
+            assert not bad, (bad, {k_: round(e, 4) for k_, e in errs.items()})
             return
         _run(m, g, mode)
     finally:
@@ -107,9 +115,42 @@ def test_c3_dcnv3(name, mode):
         out = m(x)
         ref = g.t("out")
         if mode == "bf16":
+            # throughput mode (what bench.py --workload cfg5dcn runs): the backward of the whole block — DCNv3 sampling gradients,
+            # depth-wise conv weight gradient, offset / mask Linear gradients, group-softmax backward — against the f32 fixture in
+            # relative L2 (sampling positions come from bf16-rounded offsets; a wrong-but-finite backward gives O(1))
             assert l2_err(out.detach().cpu(), ref) < 8e-2
             (out * g.t("gup").cuda()).sum().backward()
-            assert torch.isfinite(x.grad).all()
+            errs = {"x": l2_err(x.grad.cpu(), g.t("gx0"))}
+            grads = g.group("grad")
+            gscale = max(float(v.abs().max()) for v in grads.values())
+            named = dict(m.named_parameters())
+            for kk, v in grads.items():
+                if float(v.abs().max()) < 1e-4 * gscale:      # mathematically zero in f32: only rounding noise to compare
+                    continue
+                errs[kk] = l2_err(named[kk].grad.detach().float().cpu(), v)
+            # What bf16 can reproduce here (tools/dcn_bf16_debug.py): the sampling positions are bf16-rounded offsets (spacing 2^-6 px
+            # at |offset| in [2, 4)), and d(sample)/d(position) jumps where a position crosses an integer; the few percent of samples
+            # whose rounded position lands on the other side of a grid line get an O(1) different offset gradient.  One DCNv3 deep
+            # (module fixture, n = 1 with the shortcut) that is 0.05-0.18 relative L2 on what sits behind the offset branch; every
+            # further DCNv3 in series WITHOUT a shortcut around it compounds it (the fixture's random offset weights make that branch
+            # strong; the module itself starts them at zero): n = 2 / no shortcut measures 0.2-0.3 behind the last DCNv3 and
+            # 0.5-0.9 behind both, the same at 64 channels x 40x40 x batch 4 (bf16 vs f32 of this path), i.e. not a small-fixture
+            # artefact.  Bounds: BF16_GRAD_TOL behind at most one DCNv3; further upstream a gradient must still POINT the right way
+            # (cosine > 0.5 with a norm within 2x) — a wrong-but-finite backward gives a cosine around zero.
+            deep = "noshortcut" in name and n > 1
+            tight = {k_: e for k_, e in errs.items() if not deep or k_.startswith(("cv2.", "cv3.")) or (k_.startswith("m.1.") and ".offset" not in k_
+                                                                                                        and ".dw_conv" not in k_ and ".cv1" not in k_
+                                                                                                        and ".conv." not in k_)}
+            bad = {k_: round(e, 4) for k_, e in tight.items() if not e < BF16_GRAD_TOL}
+            assert not bad, (bad, {k_: round(e, 4) for k_, e in errs.items()})
+            for k_ in errs:
+                if k_ in tight:
+                    continue
+                a = (x.grad.cpu() if k_ == "x" else named[k_].grad.detach().float().cpu()).double().flatten()
+                b = (g.t("gx0") if k_ == "x" else grads[k_]).double().flatten()
+                cos = float((a @ b) / (a.norm() * b.norm()))
+                ratio = float(a.norm() / b.norm())
+                assert cos > 0.5 and 0.5 < ratio < 2.0, (k_, cos, ratio)
             return
         assert rel_err(out.detach().cpu(), ref) < 1e-4, rel_err(out.detach().cpu(), ref)
         (out * g.t("gup").cuda()).sum().backward()

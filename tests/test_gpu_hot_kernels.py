@@ -120,15 +120,18 @@ def test_tiled_igemm_hot_instantiations(case):
 
 
 # point-wise streaming kernel: K-row widths 128 / 256 / 512 bytes, 64 / 128 / 256 output channels, M >= 65 536 pixels
+# (the last field of the recorded name is the store path: "ts" = LDS-transposed 16-byte stores, "direct" = register-layout stores)
 PW = [
-    ("pw_rb128_f32", "f32", 4, 32, 128, "pw_kernel<f32,128,8,4>"),
-    ("pw_rb256_f32", "f32", 4, 64, 128, "pw_kernel<f32,256,8,4>"),
-    ("pw_rb512_ct4_f32", "f32", 4, 128, 64, "pw_kernel<f32,512,4,4>"),
-    ("pw_rb512_nw8_f32", "f32", 4, 128, 128, "pw_kernel<f32,512,8,8>"),
-    ("pw_rb128_bf16", "bf16", 4, 64, 128, "pw_kernel<bf16,128,8,4>"),
-    ("pw_rb256_bf16", "bf16", 4, 128, 128, "pw_kernel<bf16,256,8,4>"),
-    ("pw_rb256_c256_bf16", "bf16", 4, 128, 256, "pw_kernel<bf16,256,8,4>"),
-    ("pw_rb512_bf16", "bf16", 4, 256, 64, "pw_kernel<bf16,512,4,4>"),
+    ("pw_rb128_f32", "f32", 4, 32, 128, "pw_kernel<f32,128,8,4,direct>"),
+    ("pw_rb256_f32", "f32", 4, 64, 128, "pw_kernel<f32,256,8,4,direct>"),
+    ("pw_rb512_ct4_f32", "f32", 4, 128, 64, "pw_kernel<f32,512,4,4,direct>"),
+    ("pw_rb512_nw8_f32", "f32", 4, 128, 128, "pw_kernel<f32,512,8,8,direct>"),
+    ("pw_rb128_bf16", "bf16", 4, 64, 128, "pw_kernel<bf16,128,8,4,ts>"),
+    ("pw_rb256_bf16", "bf16", 4, 128, 128, "pw_kernel<bf16,256,8,4,ts>"),
+    ("pw_rb256_c256_bf16", "bf16", 4, 128, 256, "pw_kernel<bf16,256,8,4,ts>"),
+    ("pw_rb512_bf16", "bf16", 4, 256, 64, "pw_kernel<bf16,512,4,4,ts>"),
+    # 256 -> 128 @160^2: the 8-wave instantiation of the benchmark's head (8 launches per step)
+    ("pw_rb512_nw8_bf16", "bf16", 4, 256, 128, "pw_kernel<bf16,512,8,8,ts>"),
 ]
 
 
@@ -148,6 +151,56 @@ def test_wgrad2_pipelined_kernel_against_oracle(c1, c2, k, expk):
     got, ref, kern = _case("bf16", 8, c1, c2, k, 1, 160, 160)
     assert kern["wgrad"] == expk, kern
     _check(got, ref, "bf16", expk)
+
+
+def test_bf16_dgrad_accumulate_variants_against_oracle():
+    """the ACCUMULATING input-gradient launches of throughput mode (second writer of a shared gradient: read-modify-write
+    epilogue, non-transposed "direct" stores in the point-wise kernel) against the CPU oracle: an un-fused script C3 — cv1 and cv2
+    read the same x, so cv1's dgrad (the later one in backward order) adds into what cv2's wrote; 128 channels at 4x160x160
+    selects the streaming kernel for the 1x1 layers and the ring kernel for the 3x3"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd import config
+    from oracle.fill import fill_state_dict
+    ydl.set_compute_dtype("bf16")
+    config.set_fuse_siblings(False)
+    try:
+        m = ydl.C3(128, 128, 1)
+        sd = m.state_dict()
+        fill_state_dict(sd, 17, bn_stats=False)
+        for k in sd:
+            if sd[k].dim() == 4:
+                sd[k] = sd[k].bfloat16().float()
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        rs = np.random.RandomState(4)
+        x = torch.from_numpy((rs.standard_normal((4, 128, 160, 160)) + 0.25).astype(np.float32)).bfloat16().float()
+        gup = torch.from_numpy(rs.standard_normal((4, 128, 160, 160)).astype(np.float32))
+        xg = x.cuda().requires_grad_(True)
+        out = m(xg)
+        (out * gup.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        last_dgrad = L.last_kernel(1)
+        # cv1's dgrad comes last and adds into what cv3's residual branch and cv2's dgrad wrote: accumulate => direct stores
+        assert last_dgrad.startswith("pw_kernel<bf16,") and last_dgrad.endswith(",direct>"), last_dgrad
+        ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+        run = {k: v.clone() for k, v in sd.items()}
+        run.update(ps)
+        xr = x.clone().requires_grad_(True)
+        torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    finally:
+        config.set_fuse_siblings(True)
+        ydl.set_compute_dtype("bf16")
+    # the oracle keys blocks by prefix: wrap the block's state under "b."
+    run = {"b." + k: v for k, v in run.items()}
+    o = R.c3_script(run, "b", xr, 1, True)
+    (o * gup).sum().backward()
+    assert l2_err(out.detach().cpu(), o.detach()) < 3e-2, l2_err(out.detach().cpu(), o.detach())
+    assert l2_err(xg.grad.detach().cpu(), xr.grad) < 5e-2, l2_err(xg.grad.detach().cpu(), xr.grad)
+    named = dict(m.named_parameters())
+    for k, p in ps.items():
+        e = l2_err(named[k].grad.detach().float().cpu(), p.grad)
+        assert e < 6e-2, (k, e)
 
 
 def test_bn_finalize_two_level_merge_against_oracle():

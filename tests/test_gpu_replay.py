@@ -1,0 +1,185 @@
+"""The launch-list replay of the training step (yolo_dual_amd/replay.py, csrc/replay.cpp) against the eager step: the same kernels
+with the same arguments on the same two streams, so with deterministic weight gradients the trajectories are equal bit for bit —
+losses, parameters, BatchNorm buffers, momentum and the EMA shadow.  The private pool is poisoned after the recording pass: any
+device write of the step that did not go through the recorded list would leave garbage where a replay reads."""
+import os
+
+import pytest
+import torch
+import yaml
+
+from oracle.fill import fill_state_dict
+
+pytestmark = pytest.mark.gpu
+CW = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
+CFG = os.path.join(os.path.dirname(__file__), "..", "yolo_dual_amd", "cfg")
+
+
+def _cfg(name="yolov5_seg.yaml"):
+    cfg = yaml.safe_load(open(os.path.join(CFG, name)))
+    for sec in ("backbone", "head"):
+        for l in cfg[sec]:
+            l[2] = {"C3_DCN": "C3", "C2f_DCN": "C2f"}.get(l[2], l[2])
+    return cfg
+
+
+def _setup(mode, cfg_name="yolov5_seg.yaml", cls="YOLOv5Seg", size=128, bs=4, kind="dice"):
+    import yolo_dual_amd as ydl
+    ydl.set_compute_dtype(mode)
+    m = getattr(ydl, cls)(_cfg(cfg_name))
+    m.img_size = [size, size]
+    sd = m.state_dict()
+    fill_state_dict(sd, 5, bn_stats=False)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.937, weight_decay=5e-4)
+    crit = ydl.SegmentationLoss(12, 0.0, CW, kind, sync=False)
+    gen = torch.Generator("cuda").manual_seed(3)
+    xs = [torch.rand(bs, 3, size, size, device="cuda", generator=gen) for _ in range(3)]
+    ts = [torch.randint(0, 12, (bs, size, size), device="cuda", generator=gen) for _ in range(3)]
+    return m, opt, crit, xs, ts
+
+
+def _state(m, opt):
+    out = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out["__momentum"] = opt.mom_arena.detach().clone()
+    out["__ema"] = opt.ema_arena.detach().clone()
+    return out
+
+
+@pytest.mark.parametrize("mode,cfg_name,cls,kind", [("bf16", "yolov5_seg.yaml", "YOLOv5Seg", "dice"), ("f32", "yolov5_seg.yaml", "YOLOv5Seg", "dice"),
+                                                    ("bf16", "yolov8_seg.yaml", "YOLOv8Seg", "jaccard"),
+                                                    ("bf16", "yolov9_seg.yaml", "YOLOv9Seg", "dice")])
+def test_replayed_step_equals_the_eager_step_bit_for_bit(mode, cfg_name, cls, kind):
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
+    from yolo_dual_amd.replay import ReplayedTrainStep
+    config.set_deterministic(True)          # bf16 default = atomic weight gradients (arrival-order sums): not comparable bit for bit
+    try:
+        res = {}
+        for how in ("eager", "replay"):
+            m, opt, crit, xs, ts = _setup(mode, cfg_name, cls, kind=kind)
+            x, t = xs[0].clone(), ts[0].clone()            # the static batch tensors
+            losses = []
+            if how == "eager":
+                for st in range(7):
+                    x.copy_(xs[st % 3]); t.copy_(ts[st % 3])
+                    opt.zero_grad()
+                    total, items = crit(m(x), t)
+                    total.backward()
+                    opt.step()
+                    losses.append(float(items[0]))
+            else:
+                # the constructor runs 2 eager warm-up steps + the recorded step on the batch in (x, t); to follow the eager schedule
+                # the static tensors are refreshed through a forward pre-hook during those three steps
+                step_no = [0]
+                def pre(_mod, _inp):
+                    i = step_no[0]
+                    x.copy_(xs[i % 3]); t.copy_(ts[i % 3])
+                    step_no[0] += 1
+                h = m.register_forward_pre_hook(pre)
+                r = ReplayedTrainStep(m, crit, opt, x, t, warmup=2)
+                h.remove()
+                assert step_no[0] == 3
+                losses = [None, None, float(r.loss_items[0])]
+                freed = r.poison()
+                assert freed > (1 << 20), freed                # the step's activations went back to the private pool
+                for st in range(3, 7):
+                    x.copy_(xs[st % 3]); t.copy_(ts[st % 3])
+                    items = r.step()
+                    losses.append(float(items[0]))
+                assert r.launches > 50
+                nbt = int(m.state_dict()["backbone.0.bn.num_batches_tracked"])
+                assert nbt == 7 and opt.updates == 7, (nbt, opt.updates)
+            torch.cuda.synchronize()
+            res[how] = (losses, _state(m, opt))
+        le, lr_ = res["eager"][0], res["replay"][0]
+        assert le[2:] == lr_[2:], (le, lr_)
+        for k, v in res["eager"][1].items():
+            assert torch.equal(v, res["replay"][1][k]), k
+    finally:
+        config.set_deterministic(None)
+        ydl.set_compute_dtype("bf16")
+
+
+def test_replay_keeps_two_streams_and_costs_little_host_time():
+    """the recorded list names both HIP streams of the eager step (weight gradients and the dead head branch run beside the main
+    chain), and issuing it costs a fraction of the eager step's host time"""
+    import time
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd.replay import ReplayedTrainStep
+    m, opt, crit, xs, ts = _setup("bf16", size=256, bs=4)
+    x, t = xs[0][:, :, :256, :256].contiguous(), ts[0]
+    try:
+        def eager():
+            opt.zero_grad()
+            total, _ = crit(m(x), t)
+            total.backward()
+            opt.step()
+        for _ in range(3):
+            eager()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eager()
+        t_eager = (time.perf_counter() - t0) / 5
+        torch.cuda.synchronize()
+        r = ReplayedTrainStep(m, crit, opt, x, t, warmup=1)
+        assert len(r.rec.handles) == 2, r.rec.handles
+        for _ in range(2):
+            r.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r.step()
+        t_replay = (time.perf_counter() - t0) / 5
+        torch.cuda.synchronize()
+        print(f"[replay] host time per step: eager {t_eager * 1e3:.2f} ms, launch list {t_replay * 1e3:.2f} ms ({r.launches} calls)")
+        assert t_replay < 0.5 * t_eager, (t_replay, t_eager)
+    finally:
+        ydl.set_compute_dtype("bf16")
+
+
+def test_replayed_step_of_the_dcnv3_model():
+    """BASELINE configs[4] with C3_DCNV3 wired in: the DCNv3 backward adds its input gradient with f32 atomics (arrival order), so
+    two EAGER runs of this model already differ in the last bits and drift apart step by step; the replay is therefore compared
+    on ONE step from a synchronised state — the forward is deterministic (loss equal bit for bit), the gradient arena agrees to
+    atomic-order rounding"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
+    from yolo_dual_amd.replay import ReplayedTrainStep
+    from tests.util import l2_err
+    config.set_deterministic(True)
+    try:
+        mA, oA, cA, xs, ts = _setup("bf16", "yolov9_dcnv3_seg.yaml", "YOLOv9Seg")
+        mB, oB, cB, _, _ = _setup("bf16", "yolov9_dcnv3_seg.yaml", "YOLOv9Seg")
+        x, t = xs[0].clone(), ts[0].clone()
+        r = ReplayedTrainStep(mB, cB, oB, x, t, warmup=2)
+        r.poison()
+        r.step()
+        with torch.no_grad():                         # parameters + BatchNorm buffers, momentum, EMA shadow
+            oA.params_arena.copy_(oB.params_arena); oA.mom_arena.copy_(oB.mom_arena); oA.ema_arena.copy_(oB.ema_arena)
+        oA._has_buf = {id(pa): oB._has_buf.get(id(pb), False) for (pa, *_a), (pb, *_b) in zip(oA._slots, oB._slots)}
+        config.bump_weight_epoch()
+        x.copy_(xs[1]); t.copy_(ts[1])
+        eager_grads = []
+        for _ in range(3):                            # the eager path's own run-to-run noise from identical state
+            oA.zero_grad()
+            total, items = cA(mA(x), t)
+            total.backward()
+            torch.cuda.synchronize()
+            eager_grads.append(oA.grads_arena.detach().cpu().clone())
+        noise = max(l2_err(eager_grads[1], eager_grads[0]), l2_err(eager_grads[2], eager_grads[0]))
+        oB.prepare_step(1.0)
+        r.rec.run(0, r._n_fb)                         # forward + backward of the list only
+        torch.cuda.synchronize()
+        assert float(items[0]) == float(r.loss_items[0])
+        got = l2_err(oB.grads_arena.cpu(), eager_grads[0])
+        print(f"[replay dcn] gradient arena: replay vs eager {got:.2e}, eager vs eager {noise:.2e}")
+        assert got <= 3 * noise + 1e-6, (got, noise)
+        touched_a = [bool(getattr(p, "_ydl_touched", False)) for p, *_ in oA._slots]
+        touched_b = [bool(getattr(p, "_ydl_touched", False)) for p, *_ in oB._slots]
+        assert touched_a == touched_b
+    finally:
+        config.set_deterministic(None)
+        ydl.set_compute_dtype("bf16")

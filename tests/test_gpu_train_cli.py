@@ -65,6 +65,14 @@ def test_fused_inference_matches_eval_mode(mode):
             ref = m(x)
             m.fuse()
             got = m(x)
+        # the checker: the CPU oracle in eval mode (BatchNorm on its running statistics, as validate.run(model=ema.ema) uses the
+        # model, seg_diceloss_yolov5.py:1155) — eval-mode kernels AND the BN-folded kernels (utils/torch_utils.py:248-269,
+        # models/common.py:61-64) against it, not only against each other
+        from oracle import ref_cpu as R
+        want = R.script_model_forward({k: v.clone() for k, v in sd.items()}, cfg, x.cpu(), (96, 96), train=False)
+        for name, t_ in (("eval", ref), ("fused", got)):
+            e = float((t_.cpu() - want).abs().max() / want.abs().max()) if mode == "f32" else float((t_.cpu() - want).norm() / want.norm())
+            assert e < (1e-4 if mode == "f32" else 5e-2), (name, e)
         # bf16: the folded weights w * gamma/sigma are rounded to bf16 once more than w itself; compared in relative L2
         err = float((got - ref).abs().max()) if mode == "f32" else float((got - ref).norm() / ref.norm())
         assert err < (2e-5 if mode == "f32" else 5e-2), err
@@ -74,5 +82,58 @@ def test_fused_inference_matches_eval_mode(mode):
             a = c(xx)
             b = c.forward_fuse(xx)
         assert float((a - b).abs().max()) < (1e-5 if mode == "f32" else 5e-2)
+    finally:
+        ydl.set_compute_dtype("bf16")
+
+
+def test_freeze_keeps_frozen_parameters_bitwise_unchanged():
+    """``--freeze N`` (seg_diceloss_yolov5.py:955-959: requires_grad = False for backbone.0 .. backbone.N-1): frozen parameters get no
+    gradient kernel and are never marked touched, so the fused SGD/EMA step leaves them — weights, BN affine, momentum — bit for
+    bit unchanged over two optimizer steps (no weight decay, no momentum), while the layers behind them move.  The frozen layers'
+    BatchNorm running statistics still advance (train mode), as in the reference."""
+    import train_seg
+    import yolo_dual_amd as ydl
+    ydl.set_compute_dtype("f32")
+    try:
+        opt = train_seg.parse_opt(["--batch-size", "2", "--imgsz", "64", "--freeze", "3"])
+        model, _ = train_seg.build_model(opt)
+        model = model.cuda().train()
+        freeze = [f"backbone.{i}." for i in range(3)]
+        for k, v in model.named_parameters():
+            v.requires_grad = not any(x in k for x in freeze)
+        optim = ydl.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4)
+        crit = ydl.SegmentationLoss(12, 0.0, None, "dice")
+        before = {k: v.detach().clone() for k, v in model.named_parameters()}
+        rm0 = model.state_dict()["backbone.0.bn.running_mean"].clone()
+        gen = torch.Generator("cuda").manual_seed(0)
+        for _ in range(2):
+            x = torch.rand(2, 3, 64, 64, device="cuda", generator=gen)
+            t = torch.randint(0, 12, (2, 64, 64), device="cuda", generator=gen)
+            optim.zero_grad()
+            loss, _ = crit(model(x), t)
+            loss.backward()
+            frozen_touched = [k for k, p in model.named_parameters() if any(f in k for f in freeze) and getattr(p, "_ydl_touched", False)]
+            assert not frozen_touched, frozen_touched
+            optim.step()
+        moved = 0
+        for k, v in model.named_parameters():
+            if any(f in k for f in freeze):
+                assert torch.equal(v.detach(), before[k]), k
+            elif not torch.equal(v.detach(), before[k]):
+                moved += 1
+        assert moved > 20, moved
+        assert not torch.equal(model.state_dict()["backbone.0.bn.running_mean"], rm0)
+        # a frozen sibling pair inside a trainable model, and a frozen layer in the middle (its input still needs a gradient)
+        for k, v in model.named_parameters():
+            v.requires_grad = not k.startswith("backbone.4.cv1.")
+        before = {k: v.detach().clone() for k, v in model.named_parameters()}
+        optim.zero_grad()
+        loss, _ = crit(model(x), t)
+        loss.backward()
+        optim.step()
+        for k, v in model.named_parameters():
+            if k.startswith("backbone.4.cv1."):
+                assert torch.equal(v.detach(), before[k]), k
+        assert not torch.equal(model.backbone[0].conv.weight.detach(), before["backbone.0.conv.weight"])
     finally:
         ydl.set_compute_dtype("bf16")

@@ -95,6 +95,17 @@ SIGNATURES = {
     "ydl_cast_to_f32": (_i, [_i, _vp, _vp, _i64, _i, _vp]),
     "ydl_letterbox_image": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "ydl_letterbox_mask": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "ydl_fill_zero": (_i, [_vp, _i64, _vp]),
+    "ydl_zero2d": (_i, [_i, _vp, _i, _i64, _i, _vp]),
+    "ydl_replay_create": (_vp, []),
+    "ydl_replay_destroy": (None, [_vp]),
+    "ydl_replay_fn_count": (_i, []),
+    "ydl_replay_fn_name": (C.c_char_p, [_i]),
+    "ydl_replay_add_call": (_i, [_vp, _i, C.POINTER(_i64), _i, _i]),
+    "ydl_replay_add_event_record": (_i, [_vp, _i, _i]),
+    "ydl_replay_add_event_wait": (_i, [_vp, _i, _i]),
+    "ydl_replay_size": (_i, [_vp]),
+    "ydl_replay_run": (_i, [_vp, _i, _i, C.POINTER(_vp), _i]),
 }
 
 _lib = None
@@ -178,6 +189,16 @@ def profile_end():
 
 
 _LAUNCHES = [0]
+_RECORDER = None        # yolo_dual_amd.replay.Recorder while a step is being recorded into a launch list
+
+
+def set_recorder(r) -> None:
+    global _RECORDER
+    _RECORDER = r
+
+
+def recorder():
+    return _RECORDER
 
 
 def launch_count() -> int:
@@ -188,6 +209,8 @@ def launch_count() -> int:
 def call(name: str, *args):
     """Call an int-returning entry point and raise on error."""
     _LAUNCHES[0] += 1
+    if _RECORDER is not None:
+        _RECORDER.add(name, args)       # the call is recorded AND executed: the recording pass is a real step
     if _PROFILE is None:
         check(getattr(lib(), name)(*args), name)
         return

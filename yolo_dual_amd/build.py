@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libydl_hip.so")
-SOURCES = ["err.cpp", "igemm.hip", "bn.hip", "spatial.hip", "loss.hip", "optim.hip", "dcnv3.hip", "dcn_blocks.hip", "input.hip"]
+SOURCES = ["err.cpp", "replay.cpp", "igemm.hip", "bn.hip", "spatial.hip", "loss.hip", "optim.hip", "dcnv3.hip", "dcn_blocks.hip", "input.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
@@ -26,7 +26,7 @@ def _stale(out: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "ydl.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "ydl.h"), os.path.join(CSRC, "replay_table.inc")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -1142,15 +1142,17 @@ template <typename T, int RB, int CT, int NW>
 static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int fam) {
     YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, true>), 160 * 1024);
     YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, false>), 160 * 1024);
-    {
-        static const std::string nm = std::string("pw_kernel<") + (sizeof(T) == 4 ? "f32" : "bf16") + "," + std::to_string(RB) + "," +
-                                      std::to_string(CT) + "," + std::to_string(NW) + ">";
-        ydl_note_kernel(fam, nm.c_str());
-    }
     PwArgs a2 = a;
     static const int no_t = getenv("YDL_PW_NOTSTORE") ? atoi(getenv("YDL_PW_NOTSTORE")) : 0;
     // (bf16 only: the f32 instantiations lose an occupancy step or spill with the extra staging code; parity mode keeps direct stores)
     a2.tstore = (sizeof(T) == 2 && !a.accumulate && !no_t && pl.smem + pl.tstage <= 158 * 1024) ? 1 : 0;
+    {
+        // the store path is part of the recorded name: "ts" = per-wave LDS-transposed 16-byte stores, "direct" = register-layout stores
+        static const std::string base = std::string("pw_kernel<") + (sizeof(T) == 4 ? "f32" : "bf16") + "," + std::to_string(RB) + "," +
+                                        std::to_string(CT) + "," + std::to_string(NW);
+        static const std::string nm_ts = base + ",ts>", nm_direct = base + ",direct>";
+        ydl_note_kernel(fam, (a2.tstore ? nm_ts : nm_direct).c_str());
+    }
     if (a2.tstore) pw_kernel<T, RB, CT, NW, true><<<pl.grid_m, NW * 64, pl.smem + pl.tstage, st>>>(a2);
     else pw_kernel<T, RB, CT, NW, false><<<pl.grid_m, NW * 64, pl.smem, st>>>(a2);
     YDL_LAUNCH_CHECK();
@@ -1215,6 +1217,9 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
     }
     dim3 grid(mtiles * a.grid_n);
     a.grid_m = mtiles;
+    // the weight operand marks rows beyond Cout and K-steps beyond the end with a 0xF0000000 offset that must stay out of range
+    // (>= bytesB) after the 32-bit additions of a row offset, a tap offset and a channel-block offset, each < bytesB
+    YDL_CHECK(a.bytesB < 0x08000000u, "ring kernel: weight matrix of 128 MiB or more is not supported");
     {
         // tile order (speed only): which operand would be re-fetched from beyond L2?  channel-tile-fastest streams the whole
         // weight matrix once per pixel tile when it does not fit the XCD's L2; pixel-tile-fastest keeps one weight slab in

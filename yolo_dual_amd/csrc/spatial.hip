@@ -637,3 +637,38 @@ extern "C" int ydl_channel_dot(int dtype, const void* a, int lda, const void* b,
     YDL_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// zero fills (the taped region issues no ATen kernel; these are recordable entry points like every other launch)
+// ------------------------------------------------------------------------------------------------------
+extern "C" int ydl_fill_zero(void* dst, int64_t bytes, void* stream) {
+    YDL_CHECK(dst != nullptr || bytes == 0, "null destination");
+    YDL_CHECK(bytes >= 0, "negative size");
+    if (bytes == 0) return 0;
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)bytes, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        ydl_set_error(std::string("ydl_fill_zero: hipMemsetAsync failed: ") + hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void zero2d_kernel(T* __restrict__ dst, int ldd, long long npix, int C) {
+    const long long total = npix * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long pix = i / C;
+        int c = (int)(i - pix * C);
+        dst[pix * ldd + c] = (T)0;
+    }
+}
+extern "C" int ydl_zero2d(int dtype, void* dst, int ldd, int64_t npix, int C, void* stream) {
+    YDL_CHECK(dst && ldd >= C && C > 0 && npix >= 0, "bad arguments");
+    if (npix == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (ldd == C) return ydl_fill_zero(dst, npix * C * (int64_t)esize(dtype), stream);
+    int grid = sgrid(npix * C);
+    if (dtype == YDL_F32) zero2d_kernel<float><<<grid, 256, 0, st>>>((float*)dst, ldd, npix, C);
+    else zero2d_kernel<unsigned short><<<grid, 256, 0, st>>>((unsigned short*)dst, ldd, npix, C);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

@@ -176,7 +176,7 @@ class _YamlSegModel(YdlModule):
             outs.append(x)
         n_head = len(self.head)
         from . import config as _cfg
-        from .tape import side_stream
+        from .tape import side_stream, stream_wait
         use_side = bool(self._dead_head) and _cfg.overlap_wgrad()
         main = torch.cuda.current_stream()
         side = side_stream(tape.device) if use_side else None
@@ -188,7 +188,7 @@ class _YamlSegModel(YdlModule):
                 # (A fork per layer put two event waits back to back on the side stream whenever a dead layer launched
                 # nothing — a virtual concat — and the captured HIP graph then replayed with broken ordering.)
                 if (i == 0 or (i - 1) not in self._dead_head) and L.launch_count() != fork_mark:
-                    side.wait_stream(main)
+                    stream_wait(side, main)
                     fork_mark = L.launch_count()
                 with torch.cuda.stream(side):
                     outs.append(layer._fwd(tape, inp) if not isinstance(layer, Softmax) else tape.softmax(inp))
@@ -200,7 +200,7 @@ class _YamlSegModel(YdlModule):
                     p = tape.softmax_nchw(inp)          # final layer, already at img_size: write NCHW f32 directly
                     tape.ext = (inp, p)
                     if use_side:
-                        main.wait_stream(side)          # the dead branch has finished before the region returns
+                        stream_wait(main, side)          # the dead branch has finished before the region returns
                     return p
                 x = tape.softmax(inp)
             else:
@@ -210,7 +210,7 @@ class _YamlSegModel(YdlModule):
         if (x.LH, x.LW) != (H, W):                          # T7: always resized to the hard-coded img_size
             x = tape.resize(x, H, W, L.RESIZE_BILINEAR)
         if use_side:
-            main.wait_stream(side)
+            stream_wait(main, side)
         return x
 
     def _seed_external(self, tape: Tape, gout: torch.Tensor) -> None:

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import config
-from .tape import Tape, Var, round_up, _p, _stream
+from .tape import Tape, Var, round_up, _p, _stream, zero_
 
 __all__ = ["autopad", "Conv", "C3", "C3Common", "Bottleneck", "C2f", "C3k2", "GAM", "SPPF", "Concat", "Upsample",
            "BasicBlock", "BottleneckBlock", "SegmentHead", "run_region", "Linear", "DCNv3", "DCNV3_YoLo", "Bottleneck_DCNV3",
@@ -265,7 +265,9 @@ class Conv(YdlModule):
 
     def coeffs(self, device):
         cp = round_up(self.c2, 8)
-        buf = (torch.zeros if cp != self.c2 else torch.empty)((4, cp), dtype=torch.float32, device=device)
+        buf = torch.empty((4, cp), dtype=torch.float32, device=device)
+        if cp != self.c2:
+            zero_(buf)
         return {"mean": buf[0], "invstd": buf[1], "scale": buf[2], "shift": buf[3]}
 
     def _grad_of(self, p: nn.Parameter) -> torch.Tensor:
@@ -280,8 +282,16 @@ class Conv(YdlModule):
         return self._grad_of(p), 1
 
     def touch_bn(self) -> None:
-        config.mark_touched(self.bn.weight)
-        config.mark_touched(self.bn.bias)
+        if self.bn.weight.requires_grad:
+            config.mark_touched(self.bn.weight)
+        if self.bn.bias.requires_grad:
+            config.mark_touched(self.bn.bias)
+
+    def trainable(self):
+        """(weight, BN weight, BN bias) ``requires_grad`` flags: a frozen parameter (``--freeze``, seg_diceloss_yolov5.py:955-959)
+        gets no gradient kernel, is never marked touched and is therefore skipped by the optimizer like torch.optim.SGD skips
+        ``grad is None``"""
+        return (self.conv.weight.requires_grad, self.bn.weight.requires_grad, self.bn.bias.requires_grad)
 
     def splittable(self) -> bool:
         """the weight gradient can be written per input-channel block (``wgrad(col0=...)``): dense KRSC storage"""
@@ -301,7 +311,7 @@ class Conv(YdlModule):
                 config.mark_touched(p)
             return
         assert col0 == 0 and final
-        tmp = torch.zeros((self.c2, kk, cin_p), dtype=torch.float32, device=g.device)
+        tmp = zero_(torch.empty((self.c2, kk, cin_p), dtype=torch.float32, device=g.device), st)
         _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(tmp), st)
         if gk.is_contiguous():
             L.call("ydl_wgrad_unpad", _p(tmp), _p(gk), self.c2, kk, self.c1, 1, st)
@@ -411,12 +421,15 @@ class _S2DStem:
     def touch_bn(self) -> None:
         self.m.touch_bn()
 
+    def trainable(self):
+        return self.m.trainable()
+
     def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True) -> None:
         m = self.m
         p = m.conv.weight
         g = m._grad_of(p)
         gk = g.permute(0, 2, 3, 1)
-        tmp = torch.zeros((self.c2, self.k * self.k, round_up(self.c1, 8)), dtype=torch.float32, device=g.device)
+        tmp = zero_(torch.empty((self.c2, self.k * self.k, round_up(self.c1, 8)), dtype=torch.float32, device=g.device), st)
         _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(tmp), st)
         if gk.is_contiguous():
             L.call("ydl_wgrad_unpack_s2d", _p(tmp), _p(gk), m.c2, m.k, m.s, m.c1, 1, st)
@@ -520,7 +533,15 @@ class _FusedPair:
     def touch_bn(self) -> None:
         for which in ("gamma", "beta"):
             for p in self._grads(which):
-                config.mark_touched(p)
+                if p.requires_grad:
+                    config.mark_touched(p)
+
+    def trainable(self):
+        return self.a.trainable()
+
+    def uniform_trainable(self) -> bool:
+        """both halves frozen or both trainable (one launch writes both halves' gradients)"""
+        return self.a.trainable() == self.b.trainable()
 
     def splittable(self) -> bool:
         return self.c1 % 8 == 0
@@ -551,7 +572,7 @@ def _csp_forward(blk, tape: Tape, x: Var, add: bool) -> Var:
     pair = getattr(blk, "_pair", None)
     if pair is None:
         pair = blk._pair = _FusedPair(blk.cv1, blk.cv2)
-    fused = (config.fuse_siblings() and x.aligned() and not x.lazy and pair.still_valid() and
+    fused = (config.fuse_siblings() and x.aligned() and not x.lazy and pair.still_valid() and pair.uniform_trainable() and
              (not tape.record or pair.grads_adjacent()))
     if not fused:
         cat = tape.new(x.N, 2 * c_, x.H, x.W)
@@ -885,9 +906,10 @@ class Linear(YdlModule):
         cp = round_up(self.out_features, 8)
         key = (self.bias.data_ptr(), self.bias._version, config.weight_epoch())
         c = self._wcache
-        if c.get("bkey") != key or c.get("ones") is None or c["ones"].device != device:
+        if c.get("ones") is None or c["ones"].device != device:       # created once (a refresh below only rewrites bpad's contents)
             c["ones"] = torch.ones(cp, dtype=torch.float32, device=device)
             c["bpad"] = torch.zeros(cp, dtype=torch.float32, device=device)
+            c["bkey"] = None
         if c.get("bkey") != key:
             L.call("ydl_copy2d", L.YDL_F32, _p(self.bias.detach()), self.out_features, _p(c["bpad"]), cp, 1, self.out_features, 0,
                    _stream())
@@ -900,12 +922,14 @@ class Linear(YdlModule):
         return p.grad
 
     def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st) -> None:
+        if not self.weight.requires_grad:          # frozen: no gradient kernel, never marked touched
+            return
         g = self._grad_of(self.weight)
         cin_p = round_up(self.in_features, 8)
         if cin_p == self.in_features and g.is_contiguous():
             _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(g), st)
         else:
-            tmp = torch.zeros((self.out_features, 1, cin_p), dtype=torch.float32, device=g.device)
+            tmp = zero_(torch.empty((self.out_features, 1, cin_p), dtype=torch.float32, device=g.device), st)
             _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(tmp), st)
             L.call("ydl_wgrad_unpad", _p(tmp), _p(g), self.out_features, 1, self.in_features, 1, st)
         config.mark_touched(self.weight)

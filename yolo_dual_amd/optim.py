@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import config
-from .tape import _p, _stream
+from .tape import _p, _stream, zero_
 
 
 def _is_bn(m: nn.Module) -> bool:
@@ -113,7 +113,7 @@ class FlatSGDEMA(torch.optim.Optimizer):
                     else gflat.view(p.shape)
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # grads stay attached to the arena
-        self.grads_arena.zero_()
+        zero_(self.grads_arena)
         self.reattach()
         for p, *_ in self._slots:
             p._ydl_touched = False
@@ -130,6 +130,18 @@ class FlatSGDEMA(torch.optim.Optimizer):
         return out
 
     # ------------------------------------------------------------------ graph-capturable step
+    def ensure_hyper(self) -> None:
+        """create the device hyper-parameter vector and its pinned staging ring.  Callers that route allocations to a private pool
+        (HIP-graph capture, launch-list recording) call this BEFORE they do: a persistent tensor must not land on an address the
+        captured / recorded step uses as scratch"""
+        if getattr(self, "_hyper_ring", None) is None:
+            # ring of pinned staging buffers, each guarded by the event of its last H2D copy: the host never rewrites a
+            # buffer whose copy may still be queued behind a graph replay (one reused buffer raced with the next step's write)
+            self._hyper_ring = [(torch.empty(7, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._hyper_slot = 0
+            self._hyper_used = [False] * 8
+            self._hyper_dev = torch.empty(7, dtype=torch.float32, device=self.params_arena.device)
+
     def prepare_step(self, grad_scale: float = 1.0) -> None:
         """host half of a step: advance the EMA counter and push {lr, momentum, wd, grad_scale, ema decay} to the device
         vector the captured kernels read (call OUTSIDE the graph, before replaying it)"""
@@ -138,13 +150,7 @@ class FlatSGDEMA(torch.optim.Optimizer):
         if self.ema_arena is not None:
             self.updates += 1
             d = self.ema_decay * (1.0 - math.exp(-self.updates / self.ema_tau))
-        if getattr(self, "_hyper_ring", None) is None:
-            # ring of pinned staging buffers, each guarded by the event of its last H2D copy: the host never rewrites a
-            # buffer whose copy may still be queued behind a graph replay (one reused buffer raced with the next step's write)
-            self._hyper_ring = [(torch.empty(7, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
-            self._hyper_slot = 0
-            self._hyper_used = [False] * 8
-            self._hyper_dev = torch.empty(7, dtype=torch.float32, device=self.params_arena.device)
+        self.ensure_hyper()
         i = self._hyper_slot
         self._hyper_slot = (i + 1) % len(self._hyper_ring)
         h, ev = self._hyper_ring[i]

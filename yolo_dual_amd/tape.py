@@ -52,6 +52,41 @@ def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def stream_wait(waiter: "torch.cuda.Stream", on: "torch.cuda.Stream") -> None:
+    """``waiter`` waits for everything enqueued on ``on`` so far.  Every cross-stream edge of the taped step goes through here so
+    that a launch-list recording (yolo_dual_amd.replay) sees it."""
+    waiter.wait_stream(on)
+    rec = L.recorder()
+    if rec is not None:
+        rec.edge(on.cuda_stream, waiter.cuda_stream)
+
+
+_ZDT = {torch.float32: L.YDL_F32, torch.bfloat16: L.YDL_BF16, torch.float16: L.YDL_BF16}
+
+
+def zero_(t: torch.Tensor, st=None) -> torch.Tensor:
+    """t[...] = 0 through the C ABI (ydl_fill_zero / ydl_zero2d) on stream ``st`` (default: torch's current stream): dense
+    tensors in any dimension order, or a channel slice of an NHWC buffer seen as (N, C, H, W).  No ATen kernel runs inside a
+    taped region — a launch list replays only what went through the C ABI."""
+    if t.numel() == 0:
+        return t
+    if t.device.type != "cuda":         # host-side arenas (the data-parallel rehearsals on CPU): no device work to record
+        return t.zero_()
+    st = _stream() if st is None else st
+    es = t.element_size()
+    dense = t.is_contiguous() or (t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous())
+    if dense:
+        L.call("ydl_fill_zero", _p(t), t.numel() * es, st)
+        return t
+    if t.dim() == 4 and t.stride(1) == 1 and t.dtype in _ZDT:
+        N, C, H, W = t.shape
+        ld = t.stride(3)
+        if t.stride(2) == W * ld and (N == 1 or t.stride(0) == H * W * ld):
+            L.call("ydl_zero2d", _ZDT[t.dtype], _p(t), ld, N * H * W, C, st)
+            return t
+    raise RuntimeError(f"zero_: unsupported view (shape {tuple(t.shape)}, strides {t.stride()}, {t.dtype})")
+
+
 class Var:
     """A NHWC activation: ``t`` is a logical (N,C,H,W) torch view whose memory is [N][H][W][ld] with c fastest."""
     __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt", "rep", "alias",
@@ -128,8 +163,9 @@ class Var:
 
 def _alloc(N: int, C: int, H: int, W: int, tdtype: torch.dtype, device, zero: bool = False) -> (torch.Tensor, int):
     ld = round_up(C, 8)
-    mk = torch.zeros if (zero or ld != C) else torch.empty
-    buf = mk((N, H, W, ld), dtype=tdtype, device=device)
+    buf = torch.empty((N, H, W, ld), dtype=tdtype, device=device)
+    if zero or ld != C:
+        zero_(buf)
     return buf.permute(0, 3, 1, 2)[:, :C], ld
 
 
@@ -188,15 +224,15 @@ class Tape:
             # a slice already holds a gradient but the whole buffer does not: zero the rest, then accumulate
             for c in v.children:
                 if not c.gset:
-                    self._gbuf(c).zero_()
+                    zero_(self._gbuf(c))
             covered = sorted((c.c0, c.c0 + c.C) for c in v.children)
             pos = 0
             for a, b in covered:
                 if a > pos:
-                    g[:, pos:a].zero_()
+                    zero_(g[:, pos:a])
                 pos = max(pos, b)
             if pos < v.C:
-                g[:, pos:].zero_()
+                zero_(g[:, pos:])
             acc = 1
         v.gset = True
         return g, acc
@@ -287,7 +323,7 @@ class Tape:
         if not self._pending_wgrad:
             return
         side = side_stream(self.device)
-        side.wait_stream(torch.cuda.current_stream())
+        stream_wait(side, torch.cuda.current_stream())
         with torch.cuda.stream(side):
             st = _stream()
             for launch in self._pending_wgrad:
@@ -303,7 +339,7 @@ class Tape:
         self.bw.clear()
         self._flush_wgrads()
         if self._side_used:
-            torch.cuda.current_stream().wait_stream(side_stream(self.device))   # parameter grads complete
+            stream_wait(torch.cuda.current_stream(), side_stream(self.device))   # parameter grads complete
             self._side_used = False
         self._keep.clear()
 
@@ -356,6 +392,8 @@ class Tape:
             if out is None:
                 out = self.new(x.N, Cout, Ho, Wo)
                 out.rep = x.rep
+                if virt is None and not x.need and not any(m.trainable()):
+                    out.need = False      # frozen layer on a prefix that needs no gradient: consumers skip their dgrad into it
             elif (out.N, out.C, out.H, out.W) != (x.N, Cout, Ho, Wo):
                 raise RuntimeError("conv_bn_act: output slice has the wrong shape")
             outs = [out]
@@ -445,18 +483,26 @@ class Tape:
         if not self.train:
             raise RuntimeError("backward through eval-mode BatchNorm is not supported")
 
+        train_w, train_g, train_b = m.trainable()
+
         def bw():
             if not any(o.is_set() for (_c, _w, o) in parts):
                 return                                   # dead branch: parameters keep grad None
+            if not (x.need or train_w or train_g or train_b) and subs is None:
+                return                                   # frozen layer on a frozen prefix: nothing upstream wants a gradient
             st2 = _stream()
             dy = self.new(x.N, Cout, Ho, Wo)
-            gw, accw = m.grad_slot(self, "gamma")
-            gb, _ = m.grad_slot(self, "beta")
+            # frozen BN parameters (requires_grad False): the sums still exist (dy needs them) but land in a scratch row
+            gw, accw = m.grad_slot(self, "gamma") if train_g else (torch.empty(Cout_p, dtype=torch.float32, device=self.device), 0)
+            gb, accb = m.grad_slot(self, "beta") if train_b else (torch.empty(Cout_p, dtype=torch.float32, device=self.device), 0)
+            if accb != accw:                              # one accumulate flag serves both rows: give the scratch row defined contents
+                zero_(gw if not train_g else gb)
+                accw = 1
             for (co, cw, o) in parts:
                 cp = round_up(cw, 8)
                 dyv = dy.t if single else dy.t[:, co:co + cw]
                 if not o.is_set():                        # this half feeds nothing that reaches the loss
-                    dyv.zero_()
+                    zero_(dyv)
                     continue
                 dout = self._gbuf(o)
                 # gradient of the residual branch, written (or added) by the same kernel pass: dz for a residual joined before the
@@ -480,7 +526,9 @@ class Tape:
             if subs is not None:
                 self._bw_split(m, subs, dy, wt, Cout_p, Ho, Wo, st2)
                 return
-            if x.need and _cfg.overlap_wgrad():
+            if not train_w:
+                pass                                       # frozen weight: no weight-gradient launch, never marked touched
+            elif x.need and _cfg.overlap_wgrad():
                 # dy was allocated on the main stream and would die with this closure while the side stream still reads
                 # it: park the reference until the streams are joined at the end of run_backward (graph-capture safe,
                 # unlike Tensor.record_stream)
@@ -530,7 +578,9 @@ class Tape:
                 gv = L.ConvGeom(v.N, v.H, v.W, v.C, v.H, v.W, dy.C, 1, 1, 0, v.ld, d.ld, gv.ldw)
             jobs.append((v, c0_, gv, d))
         overlap = _cfg.overlap_wgrad() and any(v.need for (v, _c, _g, _d) in jobs)
-        if overlap:
+        if not m.trainable()[0]:
+            pass                                           # frozen weight
+        elif overlap:
             def launch(sst, jobs=jobs):
                 for i, (v, c0_, gv, d) in enumerate(jobs):
                     m.wgrad(self, ctypes.byref(gv), v, d, sst, col0=c0_, final=(i == len(jobs) - 1))
@@ -811,7 +861,7 @@ class Tape:
                 st2 = _stream()
                 dout = self._gbuf(out)
                 dov = Var(self, dout, out.ld, False)
-                if lin.bias is not None:
+                if lin.bias is not None and lin.bias.requires_grad:
                     gb = lin._grad_of(lin.bias)
                     ws = torch.empty(L.lib().ydl_channel_sum_ws_bytes(Cout) // 4, dtype=torch.float32, device=self.device)
                     L.call("ydl_channel_sum", self.dt, _p(dout), out.ld, _p(gb), _p(ws), x.npix, Cout, 1, st2)
@@ -858,18 +908,23 @@ class Tape:
                     return
                 st2 = _stream()
                 dy = self.new(x.N, C, x.H, x.W)
-                gw, accw = m.grad_slot(self, "gamma")
-                gb, _ = m.grad_slot(self, "beta")
+                train_w, train_g, train_b = m.trainable()
+                gw, accw = m.grad_slot(self, "gamma") if train_g else (torch.empty(cp, dtype=torch.float32, device=self.device), 0)
+                gb, accb = m.grad_slot(self, "beta") if train_b else (torch.empty(cp, dtype=torch.float32, device=self.device), 0)
+                if accb != accw:
+                    zero_(gw if not train_g else gb)
+                    accw = 1
                 ws2 = torch.empty(L.lib().ydl_bn_bwd_ws_bytes(npix, cp) // 4, dtype=torch.float32, device=self.device)
                 L.call("ydl_bn_act_bwd", self.dt, _p(y.t), y.ld, _p(self._gbuf(out)), out.ld, _p(out.t), out.ld,
                        _p(m.bn.weight), _p(cf["mean"]), _p(cf["invstd"]), _p(cf["scale"]), _p(cf["shift"]), L.RES_NONE, act,
                        _p(dy.t), dy.ld, None, 0, _p(gw), _p(gb), accw, _p(ws2), npix, C, cp, st2)
                 m.touch_bn()
-                gk = m.grad_dw()
-                ws3 = torch.empty(L.lib().ydl_dwconv_wgrad_ws_bytes(C, k) // 4, dtype=torch.float32, device=self.device)
-                L.call("ydl_dwconv_wgrad", self.dt, _p(x.t), x.ld, _p(dy.t), dy.ld, _p(gk), _p(ws3), x.N, x.H, x.W, C, k, p, st2)
-                from . import config as _cfg
-                _cfg.mark_touched(m.conv.weight)
+                if train_w:
+                    gk = m.grad_dw()
+                    ws3 = torch.empty(L.lib().ydl_dwconv_wgrad_ws_bytes(C, k) // 4, dtype=torch.float32, device=self.device)
+                    L.call("ydl_dwconv_wgrad", self.dt, _p(x.t), x.ld, _p(dy.t), dy.ld, _p(gk), _p(ws3), x.N, x.H, x.W, C, k, p, st2)
+                    from . import config as _cfg
+                    _cfg.mark_touched(m.conv.weight)
                 if x.need:
                     gx, acc = self.grad_target(x)
                     L.call("ydl_dwconv_dgrad", self.dt, _p(dy.t), dy.ld, _p(wm), _p(gx), x.ld, acc, x.N, x.H, x.W, C, k, p, st2)
@@ -915,7 +970,7 @@ class Tape:
                 if not out.is_set():
                     return
                 st2 = _stream()
-                gin = torch.zeros(xd.shape, dtype=torch.float32, device=self.device)
+                gin = zero_(torch.empty(xd.shape, dtype=torch.float32, device=self.device))
                 goff = torch.empty(od.shape, dtype=torch.float32, device=self.device)
                 gmsk = torch.empty(md.shape, dtype=torch.float32, device=self.device)
                 L.call("ydl_dcnv3_bwd", self.dt, _p(xd), _p(od), _p(md), _p(self._gbuf(out)), _p(gin), _p(goff), _p(gmsk),
