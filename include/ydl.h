@@ -90,6 +90,15 @@ int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void*
 int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype);
 int ydl_conv_wgrad_det(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, float* ws, void* stream);
 
+/* Throughput-mode statistics: the same convolution, but every block ADDS its per-channel (sum, sum of squares) with f32 atomics
+ * into sums = [YDL_BN_REPLICAS][2][round_up(Cout,8)] floats (replica = block index mod YDL_BN_REPLICAS, which spreads the
+ * contention; the caller zeroes the buffer) instead of writing a partial row: no ydl_bn_finalize launch — ydl_bn_act_fwd_sums
+ * derives the coefficients from the sums itself.  The sums depend on arrival order in their last bits (run-to-run differences
+ * of 1e-7 relative in mean / variance): parity mode keeps the deterministic partial rows + ydl_bn_finalize. */
+#define YDL_BN_REPLICAS 8
+int ydl_conv_fwd_sums(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
+                      float* sums, int accumulate, void* stream);
+
 /* master weights (f32, KRSC [Cout][k*k][Cin]) -> compute copies: w [Cout][kk][Cin_p] and wt [Cin][kk][Cout_p] */
 int ydl_weight_prep(int dtype, const float* master, void* w, void* wt, int Cout, int kk, int Cin, void* stream);
 /* the same for every layer of a model in one launch; desc_dev: device array of nlayers x 8 int64
@@ -125,6 +134,25 @@ int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dout, int lddo
                    int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
                    float* dgamma, float* dbeta, int accumulate_param_grads,
                    float* ws, int64_t npix, int C, int Cp, void* stream);
+
+/* The two-launch forms on replica sums (throughput mode; see ydl_conv_fwd_sums).
+ * ydl_bn_act_fwd_sums = ydl_bn_finalize + ydl_bn_act_fwd in ONE launch: every thread derives mean / invstd / scale / shift of its
+ * channel chunk from sums = [YDL_BN_REPLICAS][2][sums_ld] (count = pixels the sums cover), block 0 also stores them (mean, invstd,
+ * scale, shift: [Cp] each, read again by the backward) and updates the running statistics.  All per-channel pointers and `sums`
+ * may point INTO wider arrays (a channel group of a fused sibling convolution): sums_ld is the row stride of the sums.
+ * ydl_bn_act_bwd_sums = ydl_bn_act_bwd without its merge launch: the reduce pass adds (sum dz, sum dz*xhat) into
+ * sums = [YDL_BN_REPLICAS][2][Cp] (zeroed by the caller), the apply pass reads them; block 0 of the apply pass stores or adds
+ * dgamma / dbeta. */
+int ydl_bn_act_fwd_sums(int dtype, const void* y, int ldy, const float* sums, int sums_ld, int64_t count,
+                        const float* gamma, const float* beta, float eps, float momentum,
+                        float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                        int replication, const void* res, int ldr, int res_mode, int act, void* out, int ldo,
+                        int64_t npix, int C, int Cp, void* stream);
+int ydl_bn_act_bwd_sums(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                        const float* mean, const float* invstd, const float* scale, const float* shift,
+                        int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                        float* dgamma, float* dbeta, int accumulate_param_grads,
+                        float* sums, int64_t npix, int C, int Cp, void* stream);
 
 /* ---- spatial ops (NHWC, channel-vectorised) -------------------------------------------------------- */
 /* max pool (k,s,p), -inf padding; idx (uint8 window offset of the arg-max, first max in scan order) is

@@ -21,11 +21,15 @@ from tests.util import l2_err, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _case(mode, N, c1, c2, k, s, H, W, seed=0, act=True):
+def _case(mode, N, c1, c2, k, s, H, W, seed=0, act=True, deterministic="keep"):
     """run Conv(c1, c2, k, s) fwd+bwd on the HIP path and on the CPU oracle; returns (got, ref, kernels)"""
     import yolo_dual_amd as ydl
     from yolo_dual_amd import _lib as L
+    from yolo_dual_amd import config
     ydl.set_compute_dtype(mode)
+    det_was = config._STATE["deterministic"]
+    if deterministic != "keep":
+        config.set_deterministic(deterministic)
     try:
         rs = np.random.RandomState(seed)
         fan_in = c1 * k * k
@@ -64,6 +68,7 @@ def _case(mode, N, c1, c2, k, s, H, W, seed=0, act=True):
                    dbeta=sd["c.bn.bias"].grad, rm=sd["c.bn.running_mean"], rv=sd["c.bn.running_var"])
         return got, ref, kern
     finally:
+        config.set_deterministic(det_was)
         ydl.set_compute_dtype("bf16")
 
 
@@ -264,3 +269,55 @@ def test_launch_attributes_are_set_per_device():
             torch.cuda.synchronize()
             assert torch.isfinite(out).all()
         assert L.lib().ydl_debug_attr_sets() > n1
+
+
+# BatchNorm statistics as atomically added replica sums (throughput mode: ydl_conv_fwd_sums -> ydl_bn_act_fwd_sums,
+# ydl_bn_act_bwd_sums; no finalize / merge launches).  Run in F32 with the non-deterministic switch so that the oracle's 1e-4 /
+# 5e-4 bounds apply to the sums path itself (bf16 runs it by default: every bf16 case above goes through it).  One case per
+# epilogue that adds into the sums: tiled kernel (3x3), point-wise streaming kernel, > 1024 blocks, Cout not a multiple of 8.
+SUMS = [("sums_tiled_k3", 4, 64, 64, 3, 1, 96, 96), ("sums_pw", 4, 64, 128, 1, 1, 160, 160), ("sums_many_blocks", 4, 16, 32, 3, 1, 192, 192),
+        ("sums_ragged_c", 3, 24, 20, 3, 2, 75, 83), ("sums_deep", 16, 256, 256, 1, 1, 20, 20)]
+
+
+@pytest.mark.parametrize("case", SUMS, ids=[c[0] for c in SUMS])
+def test_bn_replica_sums_against_oracle(case):
+    tag, N, c1, c2, k, s_, H, W = case
+    from yolo_dual_amd import config
+    assert config.bn_sums("bf16") and not config.bn_sums("f32")
+    got, ref, kern = _case("f32", N, c1, c2, k, s_, H, W, deterministic=False)
+    assert config.bn_sums("bf16")
+    _check(got, ref, "f32", tag)
+
+
+def test_bn_replica_sums_in_blocks_against_the_deterministic_path():
+    """split outputs (fused cv1|cv2 siblings: one sums buffer, two channel groups), residual joins and ReLU blocks: the replica-sums
+    path (f32, non-deterministic switch) against the deterministic partial-row path of the same kernels, which the golden block
+    tests pin to the reference"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
+    from oracle.fill import fill_state_dict
+    ydl.set_compute_dtype("f32")
+    try:
+        for make, shape in ((lambda: ydl.C3(64, 64, 1), (2, 64, 40, 44)), (lambda: ydl.C3(32, 48, 2, False), (2, 32, 33, 31)),
+                            (lambda: ydl.C2f(64, 64, 1), (2, 64, 24, 24)), (lambda: ydl.BasicBlock(32, 32), (2, 32, 28, 28)),
+                            (lambda: ydl.SPPF(64, 64), (2, 64, 20, 20))):
+            res = []
+            for det in (True, False):
+                config.set_deterministic(det)
+                m = make()
+                sd = m.state_dict()
+                fill_state_dict(sd, 11, bn_stats=True)
+                m.load_state_dict(sd)
+                m = m.cuda().train()
+                opt = ydl.FlatSGDEMA(m, lr=0.01)           # adjacent arenas: the sibling pair runs fused
+                x = torch.randn(*shape, device="cuda", generator=torch.Generator("cuda").manual_seed(2)).requires_grad_(True)
+                opt.zero_grad()
+                out = m(x)
+                (out * torch.randn(out.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(3))).sum().backward()
+                res.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.detach().clone().cpu() for p in m.parameters()] +
+                           [b.detach().clone().cpu() for b in m.buffers() if b.dtype.is_floating_point])
+            for a, b in zip(*res):
+                assert a.shape == b.shape and rel_err(b, a) < 2e-5, (shape, rel_err(b, a))
+    finally:
+        config.set_deterministic(None)
+        ydl.set_compute_dtype("bf16")

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YDL_LIB", os.path.join(_HERE, "lib", "libydl_hip.so"))   # YDL_LIB: dev override for A/B builds
 
 YDL_F32, YDL_BF16, YDL_F16 = 0, 1, 2
+BN_REPLICAS = 8          # YDL_BN_REPLICAS of ydl.h
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 RES_GRAD_ACCUMULATE = 16
@@ -37,6 +38,7 @@ SIGNATURES = {
     "ydl_conv_fwd_grid_m": (_i, [_G, _i]),
     "ydl_conv_fwd_block_m": (_i, [_G, _i]),
     "ydl_conv_fwd": (_i, [_G, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ydl_conv_fwd_sums": (_i, [_G, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_dgrad": (_i, [_G, _i, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_wgrad": (_i, [_G, _i, _vp, _vp, _vp, _vp]),
     "ydl_conv_wgrad_ws_bytes": (_i64, [_G, _i]),
@@ -47,6 +49,10 @@ SIGNATURES = {
     "ydl_bn_finalize": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ydl_bn_eval_coeffs": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "ydl_bn_act_fwd": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i64, _i, _vp]),
+    "ydl_bn_act_fwd_sums": (_i, [_i, _vp, _i, _vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i,
+                                 _i64, _i, _i, _vp]),
+    "ydl_bn_act_bwd_sums": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i,
+                                 _vp]),
     "ydl_bn_bwd_ws_bytes": (_i64, [_i64, _i]),
     "ydl_bn_act_bwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i,
                             _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
@@ -220,7 +226,7 @@ def call(name: str, *args):
     check(getattr(lib(), name)(*args), name)
     e1.record()
     g = None
-    if name in ("ydl_conv_fwd", "ydl_conv_dgrad", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
+    if name in ("ydl_conv_fwd", "ydl_conv_fwd_sums", "ydl_conv_dgrad", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
         src = args[0]._obj
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
         g._es = 4 if args[1] == YDL_F32 else 2
@@ -230,6 +236,12 @@ def call(name: str, *args):
     elif name == "ydl_bn_act_bwd":          # y and dout read once, dy written once (the two-phase kernel reads them twice)
         es = 4 if args[0] == YDL_F32 else 2
         g = float(args[22]) * args[24] * es * 3
+    elif name == "ydl_bn_act_fwd_sums":
+        es = 4 if args[0] == YDL_F32 else 2
+        g = float(args[23]) * args[25] * es * (2 + (1 if args[19] else 0))
+    elif name == "ydl_bn_act_bwd_sums":
+        es = 4 if args[0] == YDL_F32 else 2
+        g = float(args[21]) * args[23] * es * 3
     elif name in ("ydl_dcnv3_fwd", "ydl_dcnv3_bwd"):
         # algorithmic bytes: input, offsets, masks (and grad_output) read once; output / the three f32 gradients written once
         es = 4 if args[0] == YDL_F32 else 2

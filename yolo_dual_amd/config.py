@@ -91,6 +91,17 @@ def set_deterministic(on) -> None:
     _STATE["deterministic"] = None if on is None else bool(on)
 
 
+def bn_sums(dtype_name: str) -> bool:
+    """BatchNorm statistics as atomically added replica sums (ydl_conv_fwd_sums / ydl_bn_act_fwd_sums / ydl_bn_act_bwd_sums: no
+    finalize / merge launches).  Arrival-order sums: used where bitwise reproducibility is not asked for, i.e. together with the
+    atomic weight gradients of throughput mode; YDL_BN_SUMS=0 / set_bn_sums(False) keeps the deterministic partial rows"""
+    return _STATE.setdefault("bn_sums", os.environ.get("YDL_BN_SUMS", "1") != "0") and not deterministic(dtype_name)
+
+
+def set_bn_sums(on: bool) -> None:
+    _STATE["bn_sums"] = bool(on)
+
+
 def replicated_loss() -> bool:
     """SegmentationLoss evaluates a nearest-replicated prediction per stored pixel (ydl_seg_loss_rep_*)"""
     return _STATE["replicated_loss"]

@@ -524,3 +524,294 @@ extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dou
     YDL_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Throughput-mode forms on replica sums (ydl.h: ydl_conv_fwd_sums / ydl_bn_act_fwd_sums / ydl_bn_act_bwd_sums): the
+// finalize and merge launches disappear — 62 launches of 5-9 us per step on BASELINE config 2 — because every consumer thread
+// adds the YDL_BN_REPLICAS partial rows of its own channel chunk itself (L2-resident, a few hundred bytes).
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int ACT, int RES>
+__global__ __launch_bounds__(256) void bn_act_fwd_sums_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ sums, int sums_ld,
+                                                              long long count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float momentum,
+                                                              float* running_mean, float* running_var, float* mean_o, float* invstd_o,
+                                                              float* scale_o, float* shift_o, int rep, const T* __restrict__ res, int ldr,
+                                                              T* __restrict__ out, int ldo, long long npix, int C, int Cp) {
+    constexpr int V = ET<T>::V;
+    const Lay L = make_lay<V>(Cp);
+    // coefficients of the CTA's channels: ONE channel per thread (replica rows summed in double), shared through LDS — deriving
+    // them per thread for its whole chunk cost more than the streaming loop itself
+    __shared__ float s_sc[256 * 8], s_sf[256 * 8];
+    {
+        const int nch = L.cpb * V;
+        const int cbase = blockIdx.y * 256 * V;
+        const double inv_n = 1.0 / (double)count;
+        for (int j = threadIdx.x; j < nch; j += 256) {
+            const int c = cbase + j;
+            float scv = 0.f, sfv = 0.f;
+            if (c < Cp) {
+                float meanf = 0.f, invstd = 0.f;
+                double m2 = 0.0, var = 0.0;
+                if (c < C) {
+                    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < YDL_BN_REPLICAS; ++r) {
+                        s1 += (double)sums[(size_t)(2 * r) * sums_ld + c];
+                        s2 += (double)sums[(size_t)(2 * r + 1) * sums_ld + c];
+                    }
+                    const double mu = s1 * inv_n;
+                    m2 = s2 - s1 * mu;
+                    if (m2 < 0.0) m2 = 0.0;
+                    var = m2 * inv_n;
+                    meanf = (float)mu;
+                    invstd = (float)(1.0 / sqrt(var + (double)eps));
+                    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+                    scv = g * invstd;
+                    sfv = bt - meanf * scv;
+                }
+                if (blockIdx.x == 0) {
+                    mean_o[c] = meanf; invstd_o[c] = invstd; scale_o[c] = scv; shift_o[c] = sfv;
+                    if (running_mean && c < C) {
+                        const double nl = (double)count * (double)rep;
+                        const double unb = nl > 1.0 ? m2 * (double)rep / (nl - 1.0) : var;
+                        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+                        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+                    }
+                }
+            }
+            s_sc[j] = scv; s_sf[j] = sfv;
+        }
+    }
+    __syncthreads();
+    if (!L.live) return;
+    float sc[V], sf[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sc[e] = s_sc[L.cq * V + e]; sf[e] = s_sf[L.cq * V + e]; }
+    const long long stride = (long long)gridDim.x * L.R;
+    for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
+        float v[V], r[V];
+        unpack16<T>(*(const uint4*)(y + pix * ldy + L.c), v);
+        if (RES != YDL_RES_NONE) unpack16<T>(*(const uint4*)(res + pix * ldr + L.c), r);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float z = v[e] * sc[e] + sf[e];
+            if (RES == YDL_RES_BEFORE_ACT) z += r[e];
+            float o = ACT == YDL_ACT_SILU ? silu_f(z) : (ACT == YDL_ACT_RELU ? fmaxf(z, 0.f) : z);
+            if (RES == YDL_RES_AFTER_ACT) o += r[e];
+            v[e] = o;
+        }
+        *(uint4*)(out + pix * ldo + L.c) = pack16<T>(v);
+    }
+}
+
+extern "C" int ydl_bn_act_fwd_sums(int dtype, const void* y, int ldy, const float* sums, int sums_ld, int64_t count,
+                                   const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                   int replication, const void* res, int ldr, int res_mode, int act, void* out, int ldo,
+                                   int64_t npix, int C, int Cp, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16, "bad dtype");
+    YDL_CHECK(y && out && sums && mean && invstd && scale && shift, "null pointer");
+    YDL_CHECK(count > 0 && replication >= 1 && C > 0 && C <= Cp, "bad sizes");
+    YDL_CHECK(Cp % V == 0 && ldy >= Cp && ldo >= Cp && sums_ld >= Cp && sums_ld % 4 == 0, "Cp must be a chunk multiple covered by the strides");
+    YDL_CHECK((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var come together");
+    YDL_CHECK(res_mode == YDL_RES_NONE || (res != nullptr && ldr >= Cp), "residual requested but missing");
+    YDL_CHECK(aligned16(y) && aligned16(out) && aligned16(sums) && (res == nullptr || aligned16(res)), "16-byte alignment");
+    YDL_CHECK(act == YDL_ACT_NONE || act == YDL_ACT_SILU || act == YDL_ACT_RELU, "unknown activation");
+    YDL_CHECK(res_mode == YDL_RES_NONE || res_mode == YDL_RES_BEFORE_ACT || res_mode == YDL_RES_AFTER_ACT, "unknown residual mode");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid = lay_grid(npix, Cp, V, 256 * 8);
+#define YDL_FS_LAUNCH(T, A, R)                                                                                                      \
+    bn_act_fwd_sums_kernel<T, A, R><<<grid, 256, 0, st>>>((const T*)y, ldy, sums, sums_ld, (long long)count, gamma, beta, eps, momentum, \
+                                                          running_mean, running_var, mean, invstd, scale, shift, replication,         \
+                                                          (const T*)res, ldr, (T*)out, ldo, npix, C, Cp)
+#define YDL_FS_RES(T, A)                                                                  \
+    do {                                                                                  \
+        if (res_mode == YDL_RES_NONE) YDL_FS_LAUNCH(T, A, YDL_RES_NONE);                  \
+        else if (res_mode == YDL_RES_BEFORE_ACT) YDL_FS_LAUNCH(T, A, YDL_RES_BEFORE_ACT); \
+        else YDL_FS_LAUNCH(T, A, YDL_RES_AFTER_ACT);                                      \
+    } while (0)
+#define YDL_FS_ACT(T)                                                 \
+    do {                                                              \
+        if (act == YDL_ACT_SILU) YDL_FS_RES(T, YDL_ACT_SILU);         \
+        else if (act == YDL_ACT_RELU) YDL_FS_RES(T, YDL_ACT_RELU);    \
+        else YDL_FS_RES(T, YDL_ACT_NONE);                             \
+    } while (0)
+    if (dtype == YDL_F32) YDL_FS_ACT(float);
+    else YDL_FS_ACT(bf16_t);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// reduce pass: as bn_bwd_reduce_kernel, but the CTA's per-channel (sum dz, sum dz*xhat) are ADDED to replica (blockIdx.x & 7)
+// of sums; the final LDS pass is laid out one channel per thread so that a wave-instruction adds 256 contiguous bytes
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_sums_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int lddo,
+                                                                 const T* __restrict__ out, int ldo,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* __restrict__ sums, long long npix, int Cp) {
+    constexpr int V = ET<T>::V;
+    const Lay L = make_lay<V>(Cp);
+    float sb[V], sg[V], sc[V], sf[V], mu[V], is[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sb[e] = 0.f; sg[e] = 0.f; }
+    if (L.live) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sc[e] = scale[L.c + e]; sf[e] = shift[L.c + e]; mu[e] = mean[L.c + e]; is[e] = invstd[L.c + e]; }
+        const long long stride = (long long)gridDim.x * L.R;
+        long long pix = (long long)blockIdx.x * L.R + L.pl;
+        for (; pix + stride < npix; pix += 2 * stride) {
+            const uint4 y0 = *(const uint4*)(y + pix * ldy + L.c), d0 = *(const uint4*)(dout + pix * lddo + L.c);
+            const uint4 y1 = *(const uint4*)(y + (pix + stride) * ldy + L.c), d1 = *(const uint4*)(dout + (pix + stride) * lddo + L.c);
+            uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+            if (ACT == YDL_ACT_RELU) { o0 = *(const uint4*)(out + pix * ldo + L.c); o1 = *(const uint4*)(out + (pix + stride) * ldo + L.c); }
+            float dz[V], xh[V];
+            dz_xhat_q<T, ACT>(y0, d0, o0, sc, sf, mu, is, dz, xh);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
+            dz_xhat_q<T, ACT>(y1, d1, o1, sc, sf, mu, is, dz, xh);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
+        }
+        for (; pix < npix; pix += stride) {
+            float dz[V], xh[V], dvr[V];
+            dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh, dvr);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { sb[e] += dz[e]; sg[e] += dz[e] * xh[e]; }
+        }
+    }
+    __shared__ float red[256 * 2 * 8];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        red[(threadIdx.x * 2 + 0) * V + e] = sb[e];
+        red[(threadIdx.x * 2 + 1) * V + e] = sg[e];
+    }
+    __syncthreads();
+    const int cpp = Cp / V;
+    const int nch = L.cpb * V;                      // channels this CTA covers (from chunk blockIdx.y * 256)
+    float* dst = sums + (size_t)(blockIdx.x & (YDL_BN_REPLICAS - 1)) * 2 * Cp;
+    for (int j = threadIdx.x; j < nch; j += 256) {
+        const int cq = j / V, e = j - cq * V;
+        const int chunk = blockIdx.y * 256 + cq;
+        if (chunk >= cpp) continue;
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < L.R; ++l) {
+            const int tt = l * L.cpb + cq;
+            a += red[(tt * 2 + 0) * V + e];
+            b += red[(tt * 2 + 1) * V + e];
+        }
+        atomicAdd(dst + chunk * V + e, a);
+        atomicAdd(dst + Cp + chunk * V + e, b);
+    }
+}
+
+template <typename T, int ACT, int RESM>
+__global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int lddo,
+                                                                const T* __restrict__ out, int ldo,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ sums, T* __restrict__ dy, int lddy,
+                                                                T* __restrict__ dres, int lddr, int dres_acc, float* dgamma, float* dbeta,
+                                                                int acc_param, long long npix, int C, int Cp) {
+    constexpr int V = ET<T>::V;
+    const Lay L = make_lay<V>(Cp);
+    const float invM = 1.0f / (float)npix;
+    __shared__ float s_kb[256 * 8], s_kg[256 * 8];
+    {
+        const int nch = L.cpb * V;
+        const int cbase = blockIdx.y * 256 * V;
+        for (int j = threadIdx.x; j < nch; j += 256) {
+            const int c = cbase + j;
+            float db = 0.f, dg = 0.f;
+            if (c < Cp) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < YDL_BN_REPLICAS; ++r) {
+                    s1 += (double)sums[(size_t)(2 * r) * Cp + c];
+                    s2 += (double)sums[(size_t)(2 * r + 1) * Cp + c];
+                }
+                db = (float)s1; dg = (float)s2;
+                if (blockIdx.x == 0 && c < C) {
+                    if (dbeta) dbeta[c] = (acc_param ? dbeta[c] : 0.f) + db;
+                    if (dgamma) dgamma[c] = (acc_param ? dgamma[c] : 0.f) + dg;
+                }
+            }
+            s_kb[j] = db * invM; s_kg[j] = dg * invM;
+        }
+    }
+    __syncthreads();
+    if (!L.live) return;
+    float sc[V], sf[V], mu[V], is[V], kb[V], kg[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int c = L.c + e;
+        sc[e] = scale[c]; sf[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+        kb[e] = s_kb[L.cq * V + e]; kg[e] = s_kg[L.cq * V + e];
+    }
+    const long long stride = (long long)gridDim.x * L.R;
+    for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
+        float dz[V], xh[V], o[V], dv[V];
+        dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh, dv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = sc[e] * (dz[e] - kb[e] - xh[e] * kg[e]);
+        *(uint4*)(dy + pix * lddy + L.c) = pack16<T>(o);
+        if (RESM != 0) {
+            T* rp = dres + pix * lddr + L.c;
+            float r[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) r[e] = RESM == 1 ? dv[e] : dz[e];
+            if (dres_acc) {
+                float old[V];
+                unpack16<T>(*(const uint4*)rp, old);
+#pragma unroll
+                for (int e = 0; e < V; ++e) r[e] += old[e];
+            }
+            *(uint4*)rp = pack16<T>(r);
+        }
+    }
+}
+
+extern "C" int ydl_bn_act_bwd_sums(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                                   const float* mean, const float* invstd, const float* scale, const float* shift,
+                                   int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                                   float* dgamma, float* dbeta, int accumulate_param_grads,
+                                   float* sums, int64_t npix, int C, int Cp, void* stream) {
+    const int dres_acc = (res_mode & YDL_RES_GRAD_ACCUMULATE) ? 1 : 0;
+    const int rmode = res_mode & 15;
+    YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16, "bad dtype");
+    YDL_CHECK(rmode == YDL_RES_NONE || rmode == YDL_RES_AFTER_ACT || rmode == YDL_RES_BEFORE_ACT, "unknown residual mode");
+    const int resm = dres == nullptr ? 0 : (rmode == YDL_RES_AFTER_ACT ? 1 : 2);
+    YDL_CHECK(dres == nullptr || (lddr >= Cp && aligned16(dres)), "dres must be 16-byte aligned with a stride covering Cp");
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    YDL_CHECK(y && dout && dy && mean && invstd && scale && shift && sums, "null pointer");
+    YDL_CHECK(act != YDL_ACT_RELU || out != nullptr, "RELU backward needs the saved output");
+    YDL_CHECK(Cp > 0 && Cp % V == 0 && C <= Cp && ldy >= Cp && lddo >= Cp && lddy >= Cp, "bad channel geometry");
+    YDL_CHECK(aligned16(y) && aligned16(dout) && aligned16(dy) && aligned16(sums), "16-byte alignment");
+    YDL_CHECK(act == YDL_ACT_NONE || act == YDL_ACT_SILU || act == YDL_ACT_RELU, "unknown activation");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g1 = lay_grid(npix, Cp, V, BWD_MAX_PARTIALS);
+    dim3 g3 = lay_grid(npix, Cp, V, 256 * 8);
+#define YDL_BS_APPLY(T, A, RM)                                                                                                     \
+    bn_bwd_apply_sums_kernel<T, A, RM><<<g3, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale, shift, \
+                                                           mean, invstd, sums, (T*)dy, lddy, (T*)dres, lddr, dres_acc, dgamma, dbeta, \
+                                                           accumulate_param_grads, npix, C, Cp)
+#define YDL_BS_LAUNCH(T, A)                                                                                                        \
+    do {                                                                                                                           \
+        bn_bwd_reduce_sums_kernel<T, A><<<g1, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale,    \
+                                                            shift, mean, invstd, sums, npix, Cp);                                 \
+        if (resm == 0) YDL_BS_APPLY(T, A, 0);                                                                                      \
+        else if (resm == 1) YDL_BS_APPLY(T, A, 1);                                                                                 \
+        else YDL_BS_APPLY(T, A, 2);                                                                                                \
+    } while (0)
+#define YDL_BS_ACT(T)                                                   \
+    do {                                                                \
+        if (act == YDL_ACT_SILU) YDL_BS_LAUNCH(T, YDL_ACT_SILU);        \
+        else if (act == YDL_ACT_RELU) YDL_BS_LAUNCH(T, YDL_ACT_RELU);   \
+        else YDL_BS_LAUNCH(T, YDL_ACT_NONE);                            \
+    } while (0)
+    if (dtype == YDL_F32) YDL_BS_ACT(float);
+    else YDL_BS_ACT(bf16_t);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}

@@ -36,6 +36,8 @@ struct IgemmArgs {
     int accumulate;
     int M;            // N*Hg*Wg
     int stats_ld;
+    int stats_atomic; // 0: stats = per-block partial rows [gridM][2][stats_ld] (sum, M2);  1: stats = [YDL_BN_REPLICAS][2][stats_ld]
+                      //    running (sum, sum of squares), every block adds its share with f32 atomics (replica = block index & 7)
     unsigned bytesA, bytesB;   // buffer extents for the range-checked loads
     unsigned ldb_bytes;        // byte stride between weight rows (Ttot*Kc*ES when dense)
     // several output-parity classes in one launch (stride-s dgrad); ncls <= 1: the single-class fields above apply
@@ -254,9 +256,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             float m2 = 0.f;
 #pragma unroll
             for (int g2 = 0; g2 < WP; ++g2) m2 += red[g2 * BN + t];
-            float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
-            dst[n0 + t] = tot;
-            dst[p.stats_ld + n0 + t] = m2;
+            if (p.stats_atomic) {
+                float* dst = p.stats + (size_t)(mtile & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
+                atomicAdd(dst + n0 + t, tot);
+                atomicAdd(dst + p.stats_ld + n0 + t, m2 + tot * tot / (float)nvalid);      // sum of squares of this block
+            } else {
+                float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
+                dst[n0 + t] = tot;
+                dst[p.stats_ld + n0 + t] = m2;
+            }
         }
     }
 }
@@ -631,9 +639,15 @@ __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)
             q2 = q2 + qb + d * d * n * nb * rt;
             n = tot;
         }
-        float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
-        dst[n0 + t] = mu * n;
-        dst[p.stats_ld + n0 + t] = q2;
+        if (p.stats_atomic) {
+            float* dst = p.stats + (size_t)(mtile & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
+            atomicAdd(dst + n0 + t, mu * n);
+            atomicAdd(dst + p.stats_ld + n0 + t, q2 + n * mu * mu);
+        } else {
+            float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
+            dst[n0 + t] = mu * n;
+            dst[p.stats_ld + n0 + t] = q2;
+        }
     }
 }
 
@@ -881,7 +895,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
 #endif
 struct PwArgs {
     const void* X; const void* W; void* Y; float* stats;
-    int M, lda, ldc, Cout, WN, accumulate, block_m, stats_ld;
+    int M, lda, ldc, Cout, WN, accumulate, block_m, stats_ld, stats_atomic;
     unsigned bytesX, ldw_bytes;
     int tstore;          // 1: stores go through a per-wave LDS transpose (16 bytes per lane, whole pixel rows per instruction)
 };
@@ -1100,9 +1114,15 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
                 q2 = q2 + qb + d * d * n * nb * rt;
                 n = tot;
             }
-            float* dst = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld;
-            dst[ch] = mu * n;
-            dst[p.stats_ld + ch] = q2;
+            if (p.stats_atomic) {
+                float* dst = p.stats + (size_t)(blockIdx.x & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
+                atomicAdd(dst + ch, mu * n);
+                atomicAdd(dst + p.stats_ld + ch, q2 + n * mu * mu);
+            } else {
+                float* dst = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld;
+                dst[ch] = mu * n;
+                dst[p.stats_ld + ch] = q2;
+            }
         }
     }
 }
@@ -1313,7 +1333,7 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
             PwArgs q{};
             q.X = a.A; q.W = a.B; q.Y = a.C; q.stats = a.stats;
             q.M = a.M; q.lda = a.lda; q.ldc = a.ldc; q.Cout = a.Cout; q.WN = pl.WN; q.accumulate = a.accumulate;
-            q.block_m = pl.block_m; q.stats_ld = a.stats_ld; q.bytesX = a.bytesA; q.ldw_bytes = a.ldb_bytes;
+            q.block_m = pl.block_m; q.stats_ld = a.stats_ld; q.stats_atomic = a.stats_atomic; q.bytesX = a.bytesA; q.ldw_bytes = a.ldb_bytes;
             if (grid_m_out) *grid_m_out = pl.grid_m;
             return launch_pw<T>(q, pl, st, fam);
         }
@@ -1399,8 +1419,8 @@ extern "C" int64_t ydl_conv_fwd_stats_ws_bytes(const ydl_conv_geom* g, int dtype
 extern "C" int ydl_conv_fwd_grid_m(const ydl_conv_geom* g, int dtype) { int gm, bm; fwd_blocks(g, dtype, &gm, &bm); return gm; }
 extern "C" int ydl_conv_fwd_block_m(const ydl_conv_geom* g, int dtype) { int gm, bm; fwd_blocks(g, dtype, &gm, &bm); return bm; }
 
-extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
-                            float* stats_ws, int accumulate, void* stream) {
+static int conv_fwd_impl(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
+                         float* stats_ws, int stats_atomic, int accumulate, void* stream) {
     if (int e = check_geom(g, dtype)) return e;
     YDL_CHECK(aligned16(x) && aligned16(w) && aligned16(y), "pointers must be 16-byte aligned");
     IgemmArgs a{};
@@ -1413,6 +1433,7 @@ extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, co
     a.ntaps = g->k * g->k; a.Ttot = a.ntaps; a.accumulate = accumulate ? 1 : 0;
     a.M = g->N * g->Ho * g->Wo;
     a.stats_ld = round_up(g->Cout, 8);
+    a.stats_atomic = stats_atomic;
     a.ldb_bytes = (unsigned)(g->ldw * esize(dtype));
     for (int r = 0; r < g->k; ++r)
         for (int s = 0; s < g->k; ++s) {
@@ -1422,6 +1443,16 @@ extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, co
     if (int e = set_extents(a, dtype)) return e;
     hipStream_t st = (hipStream_t)stream;
     return dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 0) : dispatch_igemm<bf16_t>(a, st, 0);
+}
+
+extern "C" int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
+                            float* stats_ws, int accumulate, void* stream) {
+    return conv_fwd_impl(g, dtype, x, w, y, stats_ws, 0, accumulate, stream);
+}
+extern "C" int ydl_conv_fwd_sums(const ydl_conv_geom* g, int dtype, const void* x, const void* w, void* y,
+                                 float* sums, int accumulate, void* stream) {
+    YDL_CHECK(sums != nullptr, "null sums");
+    return conv_fwd_impl(g, dtype, x, w, y, sums, 1, accumulate, stream);
 }
 
 extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,

@@ -54,6 +54,7 @@ class _Region(torch.autograd.Function):
                                "(move the module and its inputs to cuda)")
         record = any(ctx.needs_input_grad[2:])
         tape = Tape(config.compute_dtype(), dev, fn.training, record)
+        tape._slab_hint = getattr(fn, "_ydl_slab_need", 0)
         refresh_weights(fn, tape)
         vs = [tape.input_nchw(t, lazy=not ctx.needs_input_grad[2 + i]) for i, t in enumerate(ins)]
         for i, v in enumerate(vs):
@@ -80,6 +81,8 @@ class _Region(torch.autograd.Function):
             ctx.fn._seed_external(tape, gout)
         tape.run_backward()
         gins = [tape.grad_nchw(v) if v.need else None for v in ctx.vs]
+        if tape._slab_total:
+            ctx.fn._ydl_slab_need = tape._slab_total + tape._slab_total // 8 + 1024      # next step: one slab, one memset
         ctx.tape = None
         return (None, None, *gins, *([None] * ctx.n_extra))
 

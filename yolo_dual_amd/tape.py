@@ -195,11 +195,36 @@ class Tape:
         self._pending_wgrad: List[Callable] = []   # weight-gradient launches waiting for the next fork of the side stream
         self._bw_left = 0
         self.ext = None      # (Var, tensor) of a region whose external output was written directly (softmax head)
+        self._slab = None    # zero-initialised f32 scratch of the region: accumulator rows the kernels add into (BN replica sums)
+        self._slab_off = 0
+        self._slab_total = 0         # floats handed out so far (the owner module remembers it as next step's slab size)
+        self._slab_hint = 0
+        self._main = torch.cuda.current_stream() if torch.device(device).type == "cuda" else None
 
     # ------------------------------------------------------------------ buffers
     def new(self, N: int, C: int, H: int, W: int, need: bool = True, zero: bool = False, f32: bool = False) -> Var:
         t, ld = _alloc(N, C, H, W, torch.float32 if f32 else self.tdt, self.device, zero)
         return Var(self, t, ld, need)
+
+    def zeroed(self, nfloats: int) -> torch.Tensor:
+        """``nfloats`` f32 zeros (16-byte aligned) from the region's slab: ONE memset per slab instead of one per accumulator row.
+        A slab is cleared when it is created, before any kernel that adds into it is enqueued; rows are handed out once."""
+        n = round_up(nfloats, 4)
+        self._slab_total += n
+        if self._slab is None or self._slab_off + n > self._slab.numel():
+            cap = max(1 << 18, self._slab_hint, 2 * n, 2 * (self._slab.numel() if self._slab is not None else 0))
+            self._slab = zero_(torch.empty(cap, dtype=torch.float32, device=self.device))
+            self._slab_off = 0
+            # the memset went to the CURRENT stream; rows of this slab may be used on the region's other stream too (dead head
+            # branch, deferred work): order it behind the memset.  Normally the slab is sized from the previous step's need and
+            # created once, by the first layer, before any fork.
+            cur = torch.cuda.current_stream()
+            for other in (self._main, _SIDE.get(torch.cuda.current_device())):
+                if other is not None and other.cuda_stream != cur.cuda_stream:
+                    stream_wait(other, cur)
+        out = self._slab[self._slab_off:self._slab_off + nfloats]
+        self._slab_off += n
+        return out
 
     def new_like(self, v: Var) -> Var:
         return self.new(v.N, v.C, v.H, v.W, v.need, f32=(v.dt == L.YDL_F32))
@@ -435,9 +460,13 @@ class Tape:
             geom = subs[-1][3]                       # the launch that writes the BN partials
         gp = ctypes.byref(geom)
 
+        from . import config as _cfg
+        sums_mode = self.train and _cfg.bn_sums(self.dname)      # replica sums instead of partial rows + finalize / merge launches
+        fwd_entry = "ydl_conv_fwd_sums" if sums_mode else "ydl_conv_fwd"
+
         def conv_fwd(ws_ptr):
             if subs is None:
-                L.call("ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), ws_ptr, 0, st)
+                L.call(fwd_entry if ws_ptr is not None else "ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), ws_ptr, 0, st)
                 return
             first = True
             for i, (v, c0_, r_, gv) in enumerate(subs):
@@ -450,11 +479,15 @@ class Tape:
                     L.call("ydl_resize_fwd", self.dt, L.RESIZE_BILINEAR, _p(z.t), z.ld, _p(y.t), y.ld, v.N, v.H, v.W, Ho, Wo,
                            Cout, 0.0, 0.0, st)
                 else:
-                    L.call("ydl_conv_fwd", ctypes.byref(gv), self.dt, _p(v.t), wv, _p(y.t), ws_ptr if last else None,
-                           0 if first else 1, st)
+                    L.call(fwd_entry if (last and ws_ptr is not None) else "ydl_conv_fwd", ctypes.byref(gv), self.dt, _p(v.t), wv, _p(y.t),
+                           ws_ptr if last else None, 0 if first else 1, st)
                 first = False
 
-        if self.train:
+        sums = None
+        if sums_mode:
+            sums = self.zeroed(L.BN_REPLICAS * 2 * Cout_p)
+            conv_fwd(_p(sums))
+        elif self.train:
             if subs is None:
                 nbytes, grid_m, block_m = gc[2], gc[3], gc[4]
             else:
@@ -473,6 +506,14 @@ class Tape:
         single = len(parts) == 1
         for (co, cw, o) in parts:
             cp = round_up(cw, 8)
+            if sums is not None:
+                # statistics, coefficients (kept for the backward) and running statistics of this channel group in the apply launch
+                L.call("ydl_bn_act_fwd_sums", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld, _p(sums[co:]), Cout_p, npix,
+                       _p(m.bn.weight[co:]), _p(m.bn.bias[co:]), m.bn.eps, m.bn.momentum, _p(m.bn.running_mean[co:]),
+                       _p(m.bn.running_var[co:]), _p(cf["mean"][co:]), _p(cf["invstd"][co:]), _p(cf["scale"][co:]), _p(cf["shift"][co:]),
+                       rep, _p(res.t) if res is not None else None, res.ld if res is not None else 0, res_mode, act,
+                       _p(o.t), o.ld, npix, cw, cp, st)
+                continue
             L.call("ydl_bn_act_fwd", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld,
                    _p(cf["scale"][co:]), _p(cf["shift"][co:]),
                    _p(res.t) if res is not None else None, res.ld if res is not None else 0, res_mode, act,
@@ -513,6 +554,12 @@ class Tape:
                     dres_t, dres_ld = gbuf, res.ld
                     if racc:
                         rmode = res_mode | L.RES_GRAD_ACCUMULATE
+                if sums_mode:
+                    L.call("ydl_bn_act_bwd_sums", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld, _p(dout), o.ld,
+                           _p(o.t), o.ld, _p(cf["mean"][co:]), _p(cf["invstd"][co:]), _p(cf["scale"][co:]), _p(cf["shift"][co:]),
+                           rmode, act, _p(dyv), dy.ld, _p(dres_t), dres_ld, _p(gw[co:]), _p(gb[co:]), accw,
+                           _p(self.zeroed(L.BN_REPLICAS * 2 * cp)), npix, cw, cp, st2)
+                    continue
                 nws = L.lib().ydl_bn_bwd_ws_bytes(npix, cp) // 4
                 ws2 = torch.empty(nws, dtype=torch.float32, device=self.device)
                 L.call("ydl_bn_act_bwd", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld, _p(dout), o.ld,
