@@ -143,6 +143,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
+        from yolo_dual_amd.parallel import pin_rank_to_cores
+        pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))      # each rank on its own slice of the host's cores
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(0 if args.one_gpu else local)

@@ -3,12 +3,18 @@
 
 Mirrors the argument list and the loop of unet-lite/yolo5-seg/seg_diceloss_yolov5.py (:1235-1287 CLI, :940-952 intersect-load of
 ``--weights``, :966-980 accumulate / weight-decay scaling / LambdaLR, :1084-1103 hot loop, :1204-1212 checkpoint dict, :1229
-strip_optimizer).  What the reference does around the hot path — JSON datasets, augmentation, TensorBoard, early stopping,
-DataParallel — is outside this repository's scope: batches are synthetic "blobby" masks generated on
-the device, validation is the confusion-matrix mIoU of val_diceloss.py:37-75 on held-out synthetic batches.
+strip_optimizer).  What the reference does around the hot path — JSON datasets, augmentation, TensorBoard, early stopping — is outside this
+repository's scope: batches are synthetic "blobby" masks generated on the device, validation is the
+confusion-matrix mIoU of val_diceloss.py:37-75 on held-out synthetic batches.
+
+Multi-GPU: where the reference wraps the model in nn.DataParallel (:988-992; its SyncBN branch is dead code), this entry runs one
+process per GPU under torch.distributed.run and averages gradients with yolo_dual_amd.parallel.DataParallel (RCCL all-reduce of the
+flat gradient arena, bucketed, launched from the backward hooks).  ``--batch-size`` is per GPU; BatchNorm statistics stay per
+replica and rank 0's are the ones validated and saved, as with nn.DataParallel, whose replica 0 owns the buffers.
 
     python train_seg.py --cfg yolo_dual_amd/cfg/yolov5_seg.yaml --weights '' --epochs 2 --batch-size 16 --imgsz 640
     python train_seg.py --weights runs/train-seg/last.pt --resume
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_seg.py --batch-size 16 ...
 """
 from __future__ import annotations
 
@@ -55,6 +61,10 @@ def parse_opt(argv=None):
     p.add_argument("--weight-decay", type=float, default=0.0005)
     p.add_argument("--raw-size", type=str, default="", help="WxH: synthetic samples are generated as uint8 arrays of this size and go "
                    "through the GPU letterbox (yolo_dual_amd.data.LetterboxGPU = the dataset's _resize_and_pad + /255)")
+    p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend when WORLD_SIZE > 1 (nccl = RCCL; gloo for rehearsals)")
+    p.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"])
+    p.add_argument("--dp-wire", default="f32", choices=["f32", "bf16"])
+    p.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo)")
     return p.parse_args(argv)
 
 
@@ -114,10 +124,22 @@ def train(opt) -> float:
     import yolo_dual_amd as ydl
     from torch.optim import lr_scheduler
 
+    # one process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE; the launcher starts before any GPU call)
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        from yolo_dual_amd.parallel import pin_rank_to_cores
+        pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if not torch.cuda.is_available():
         raise RuntimeError("train_seg.py runs on the GPU only (yolo_dual_amd has no CPU fallback)")
-    device = torch.device("cuda", int(opt.device) if str(opt.device).isdigit() else 0)
+    device = torch.device("cuda", 0 if opt.one_gpu else (local if world > 1 else (int(opt.device) if str(opt.device).isdigit() else 0)))
     torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        if not dist.is_initialized():
+            dist.init_process_group(opt.dist_backend, rank=rank, world_size=world)
+    main = rank == 0
     torch.manual_seed(opt.seed)
     ydl.set_compute_dtype(opt.dtype)
     os.makedirs(opt.save_dir, exist_ok=True)
@@ -131,7 +153,8 @@ def train(opt) -> float:
     if opt.weights.endswith(".pt"):                                   # seg_diceloss_yolov5.py:944-952
         ckpt = ydl.load_checkpoint(opt.weights)
         n, tot = ydl.load_weights(model, ckpt)
-        print(f"[train_seg] loaded weights: {n}/{tot} entries match")
+        if main:
+            print(f"[train_seg] loaded weights: {n}/{tot} entries match")
     model = model.to(device)
     freeze = [f"backbone.{x}." for x in (opt.freeze if len(opt.freeze) > 1 else range(opt.freeze[0]))]   # :955-959
     for k, v in model.named_parameters():
@@ -141,7 +164,11 @@ def train(opt) -> float:
     nbs = 64
     accumulate = max(round(nbs / bs), 1)                               # :970-972
     wd = opt.weight_decay * bs * accumulate / nbs
-    optimizer = ydl.smart_optimizer(model, opt.optimizer, opt.lr0, opt.momentum, wd)       # EMA is fused into the step
+    optimizer = ydl.smart_optimizer(model, opt.optimizer, opt.lr0, opt.momentum, wd, ema=main)       # EMA is fused into the step
+    dp = None
+    if world > 1:                                                                        # :988-992, as processes instead of threads
+        from yolo_dual_amd.parallel import DataParallel
+        dp = DataParallel(model, optimizer, algo=opt.dp_algo, wire=opt.dp_wire)          # broadcasts rank 0's parameters and buffers
     if opt.cos_lr:
         lf = lambda x: ((1 - math.cos(x * math.pi / epochs)) / 2) * (opt.lrf - 1) + 1     # one_cycle(1, lrf, epochs)
     else:
@@ -149,12 +176,12 @@ def train(opt) -> float:
     scheduler = lr_scheduler.LambdaLR(optimizer, lr_lambda=lf)
     best_fitness, start_epoch = 0.0, 0
     if ckpt is not None and opt.resume:
-        best_fitness, start_epoch, epochs = ydl.smart_resume(ckpt, optimizer, optimizer, opt.weights, epochs, True)
+        best_fitness, start_epoch, epochs = ydl.smart_resume(ckpt, optimizer, optimizer if main else None, opt.weights, epochs, True)
         scheduler.last_epoch = start_epoch - 1
 
     cw = class_weights(opt.class_weights, nc).to(device)
     criterion = (ydl.SegmentationLoss if loss_kind == "dice" else ydl.JaccardSegmentationLoss)(nc, opt.label_smoothing, cw)
-    gen = torch.Generator(device=device).manual_seed(1000 + opt.seed)
+    gen = torch.Generator(device=device).manual_seed(1000 + opt.seed + 7919 * rank)     # every rank draws its own batches
     palette = torch.rand(nc, 3, device=device, generator=torch.Generator(device=device).manual_seed(7))
     val_gen = torch.Generator(device=device).manual_seed(99)
     lb, raw = None, None
@@ -170,17 +197,23 @@ def train(opt) -> float:
         optimizer.zero_grad()
         for i in range(opt.steps_per_epoch):
             imgs, targets = blobby_batch(gen, bs, opt.imgsz, nc, device, palette, lb, raw)
+            stepping = (i + 1) % accumulate == 0 or i == opt.steps_per_epoch - 1       # :1095-1103
+            if dp is not None:
+                # the arena accumulates local gradients over the micro-batches; ranks exchange them once, on the step that applies them
+                dp.reducer.enabled = stepping
+                if stepping:
+                    dp.begin()
             pred = model(imgs)                                                          # :1084-1092
             loss, loss_items = criterion(pred, targets)
             loss.backward()
-            if (i + 1) % accumulate == 0 or i == opt.steps_per_epoch - 1:              # :1095-1103
-                optimizer.step()
+            if stepping:
+                optimizer.step(grad_scale=dp.finish() if dp is not None else 1.0)
                 optimizer.zero_grad()
             mloss = (mloss * i + torch.tensor(loss_items)) / (i + 1)
         scheduler.step()
         final_epoch = epoch == epochs - 1
         miou = 0.0
-        if not opt.noval or final_epoch:
+        if main and (not opt.noval or final_epoch):
             # validation on the EMA weights (validate.run(model=ema.ema), :1155): swap them in, evaluate, swap back
             live = {k: v.clone() for k, v in model.state_dict().items()}
             model.load_state_dict(optimizer.ema_state_dict())
@@ -193,19 +226,25 @@ def train(opt) -> float:
             miou, _ = cm.compute_iou()
             model.load_state_dict(live)
             ydl.config.bump_weight_epoch()
-        print(f"epoch {epoch + 1}/{epochs}  loss {mloss[0]:.4f} (ce {mloss[1]:.4f}, {loss_kind} {mloss[2]:.4f})  mIoU {miou:.4f}  "
-              f"lr {optimizer.param_groups[1]['lr']:.5f}  {time.time() - t0:.0f}s", flush=True)
+        if main:
+            print(f"epoch {epoch + 1}/{epochs}  loss {mloss[0]:.4f} (ce {mloss[1]:.4f}, {loss_kind} {mloss[2]:.4f})  mIoU {miou:.4f}  "
+                  f"lr {optimizer.param_groups[1]['lr']:.5f}  {time.time() - t0:.0f}s" + (f"  [{world} ranks]" if world > 1 else ""), flush=True)
         fi = miou                                                          # fitness = mIoU (:1197)
         if fi > best_fitness:
             best_fitness = fi
-        if (not opt.nosave) or final_epoch:
+        if main and ((not opt.nosave) or final_epoch):
             ema_sd = optimizer.ema_state_dict()
             ydl.save_checkpoint(last, ema_sd, optimizer, epoch, best_fitness)           # :1204-1209
             if fi == best_fitness:
                 ydl.save_checkpoint(best, ema_sd)                                       # :1211
-    if os.path.exists(best):
+    if main and os.path.exists(best):
         mb = ydl.strip_optimizer(best)                                                   # :1229
         print(f"[train_seg] best model saved to {best} ({mb:.1f} MB, optimizer stripped)")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        if dp is not None:
+            dp.reducer.close()
     return best_fitness
 
 

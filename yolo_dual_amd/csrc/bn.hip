@@ -691,11 +691,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_sums_kernel(const T* __rest
     const int cpp = Cp / V;
     const int nch = L.cpb * V;                      // channels this CTA covers (from chunk blockIdx.y * 256)
     float* dst = sums + (size_t)(blockIdx.x & (YDL_BN_REPLICAS - 1)) * 2 * Cp;
-    for (int j = threadIdx.x; j < nch; j += 256) {
+    // narrow tensors (few chunks per pixel) have many pixel lanes per channel: G threads share one channel's lane sum
+    // (16 channels x 128 lanes summed by 16 threads took longer than the streaming loop)
+    const int G = nch >= 256 ? 1 : 256 / nch;
+    __shared__ float part[256 * 2];
+    float a = 0.f, b = 0.f;
+    int j = threadIdx.x, grp = 0;
+    if (G > 1) { j = threadIdx.x % nch; grp = threadIdx.x / nch; }
+    if (G > 1) {
+        if (grp < G) {
+            const int cq = j / V, e = j - cq * V;
+            for (int l = grp; l < L.R; l += G) {
+                const int tt = l * L.cpb + cq;
+                a += red[(tt * 2 + 0) * V + e];
+                b += red[(tt * 2 + 1) * V + e];
+            }
+        }
+        part[threadIdx.x * 2] = a;
+        part[threadIdx.x * 2 + 1] = b;
+        __syncthreads();
+        if (threadIdx.x < nch) {
+            a = 0.f; b = 0.f;
+            for (int g2 = 0; g2 < G; ++g2) { a += part[(g2 * nch + threadIdx.x) * 2]; b += part[(g2 * nch + threadIdx.x) * 2 + 1]; }
+            const int cq = threadIdx.x / V, e = threadIdx.x - cq * V;
+            const int chunk = blockIdx.y * 256 + cq;
+            if (chunk < cpp) {
+                atomicAdd(dst + chunk * V + e, a);
+                atomicAdd(dst + Cp + chunk * V + e, b);
+            }
+        }
+        return;
+    }
+    for (j = threadIdx.x; j < nch; j += 256) {
         const int cq = j / V, e = j - cq * V;
         const int chunk = blockIdx.y * 256 + cq;
         if (chunk >= cpp) continue;
-        float a = 0.f, b = 0.f;
+        a = 0.f; b = 0.f;
         for (int l = 0; l < L.R; ++l) {
             const int tt = l * L.cpb + cq;
             a += red[(tt * 2 + 0) * V + e];

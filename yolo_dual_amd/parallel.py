@@ -67,6 +67,22 @@ def _local_ops(t: torch.Tensor):
     return to_wire, from_wire, sum_chunks
 
 
+def pin_rank_to_cores(local_rank: int, local_world: int) -> list:
+    """give each rank of a node its own slice of the CPUs this process may run on (os.sched_setaffinity): eight ranks that each
+    issue a few hundred launches per step otherwise migrate across cores and NUMA nodes.  Returns the cores chosen ([] when the
+    platform has no affinity call or there are fewer cores than ranks: nothing is changed then)."""
+    import os
+    if not hasattr(os, "sched_getaffinity") or local_world <= 1:
+        return []
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+        return []
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 class GradBucketReducer:
     def __init__(self, opt: FlatSGDEMA, bucket_bytes: int = 16 << 20, group=None, algo: str = "allreduce", wire: str = "f32"):
         if algo not in ("allreduce", "rs_ag") or wire not in ("f32", "bf16"):
@@ -154,8 +170,13 @@ class GradBucketReducer:
         """start the sum over ranks of grads_arena[a:b]; completion + write-back happen in ``_drain``"""
         view = self.opt.grads_arena[a:b]
         if view.is_cuda:        # weight gradients are produced on the side stream (tape.side_stream)
-            from .tape import side_stream
-            torch.cuda.current_stream().wait_stream(side_stream(view.device))
+            # (a bucket completed by a weight-gradient batch is launched from inside the side-stream context, which the flush
+            #  ordered behind the main stream: the collective then waits for that stream only and the main chain is not held up;
+            #  launched from the main stream it waits for the side stream first)
+            from .tape import side_stream, stream_wait
+            cur, side = torch.cuda.current_stream(), side_stream(view.device)
+            if cur.cuda_stream != side.cuda_stream:
+                stream_wait(cur, side)
         if self.algo == "allreduce" and self.wire == "f32":
             self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
@@ -255,6 +276,11 @@ class DataParallel:
                  algo: str = "allreduce", wire: str = "f32"):
         self.model, self.opt = model, opt
         self.reducer = GradBucketReducer(opt, bucket_bytes, group, algo=algo, wire=wire)
+        if self.reducer.world > 1:
+            # a bucket goes out when its last gradient launch has been ENQUEUED: weight gradients batched eight layers deep before
+            # a fork of the side stream would hold every bucket back to the end of backward (the batching exists for the eager
+            # path's host time only)
+            config.set_wgrad_batch(1)
         if broadcast and dist.is_initialized() and self.reducer.world > 1:
             dist.broadcast(opt.params_arena, src=0, group=group)     # identical replicas (params + BN buffers)
             if opt.ema_arena is not None:
