@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="keep wgrad on the main stream")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python (no launch-list replay, no HIP graph)")
+    ap.add_argument("--prioritize", type=int, default=0, help="replay the main chain on a high-priority stream, side work on low-priority ones")
     ap.add_argument("--try-hipgraph", action="store_true", help="also time the single-stream HIP-graph capture of the step")
     ap.add_argument("--profile-json", default="", help="dump the per-launch event records of the instrumented pass")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the side stream (wgrad / dead branch) into the graphs too")
@@ -222,7 +223,7 @@ def main():
         rstep, t_replay, failed = None, BIG, 0.0
         try:
             from yolo_dual_amd.replay import ReplayedTrainStep
-            rstep = ReplayedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=1)
+            rstep = ReplayedTrainStep(model, crit, opt, imgs, tgts, dp=dp, warmup=1, prioritize=bool(args.prioritize))
         except Exception as e:          # pragma: no cover
             failed = 1.0
             print(f"[bench] launch-list recording unavailable on rank {rank}: {e!r}", file=sys.stderr)
@@ -319,10 +320,10 @@ def main():
         dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, f = dom
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic_pmc.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")
-        if os.path.exists(tpath) and args.workload == "cfg2":      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))     # the newest round's counter summary
+        tpath = cands[-1] if cands else ""
+        if tpath and args.workload == "cfg2":      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command
             try:
                 tj = json.load(open(tpath))
                 ig = [k for k in tj["kernels"] if "igemm" in k["kernel"] or "pw_kernel" in k["kernel"]]

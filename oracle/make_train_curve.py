@@ -20,6 +20,7 @@ from oracle.fill import fill_state_dict  # noqa: E402
 from tests.model_shapes import script_model_state_shapes  # noqa: E402
 
 S, BS, STEPS, LR, NB = 128, 8, 600, 0.02, 16
+NVAL = 8            # held-out batches of the final evaluation (8 x 8 = 64 images, seeds 2..9)
 LRF = 0.05          # linear decay of the learning rate to LRF * LR over the run (the reference's LambdaLR shape, :976-980)
 CW = torch.tensor([1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1], dtype=torch.float32)
 
@@ -52,6 +53,7 @@ def run(eps: float, verbose: bool = True):
     pnames = [k for k in sd if k.endswith(".weight") or k.endswith(".bias")]
     xv, tv = blobby(2, BS)
     bufs, losses, mious = {}, [], []
+    held_out = [blobby(2 + i, BS) for i in range(NVAL)]          # NVAL x BS held-out images (seeds never used for training)
     for st in range(STEPS):
         x, t = blobby(100 + st % NB, BS)
         if st % NB == 0:
@@ -76,7 +78,18 @@ def run(eps: float, verbose: bool = True):
             mious.append(miou)
             if verbose:
                 print(f"eps {eps:g} step {st + 1}: loss {losses[-1]:.4f}  val mIoU {miou:.4f}", flush=True)
-    return np.array(losses), np.array(mious), np.array(ious)
+    # final evaluation on the large held-out set: one confusion matrix over all NVAL batches (val_diceloss.py:216-256 accumulates
+    # the matrix over the loader the same way)
+    cm = None
+    with torch.no_grad():
+        for xh, th in held_out:
+            ph = R.script_model_forward({k: v.clone() for k, v in sd.items()}, cfg, xh, (S, S), train=False)
+            c = R.confusion_matrix(ph.argmax(1), th, 12)
+            cm = c if cm is None else cm + c
+    miou64, ious64 = R.miou_from_confusion(cm)
+    if verbose:
+        print(f"eps {eps:g}: final val mIoU on {NVAL * BS} held-out images {miou64:.4f} (first batch alone {mious[-1]:.4f})", flush=True)
+    return np.array(losses), np.array(mious), np.array(ious), float(miou64), np.array(ious64)
 
 
 EPS = (0.0, 1e-6, -1e-6, 2e-6)
@@ -93,20 +106,21 @@ def main():
     torch.set_num_threads(a.threads)
     part = lambda i: os.path.join("/tmp", f"train_curve_part{i}.npz")
     if a.member >= 0:
-        l, m, io = run(EPS[a.member])
-        np.savez(part(a.member), losses=l, mious=m, ious=io)
+        l, m, io, m64, io64 = run(EPS[a.member])
+        np.savez(part(a.member), losses=l, mious=m, ious=io, miou64=m64, ious64=io64)
         return
-    L, M, I = [], [], []
+    L, M, I, M64, I64 = [], [], [], [], []
     for i, e in enumerate(EPS):
         if not os.path.exists(part(i)):
-            l, m, io = run(e)
-            np.savez(part(i), losses=l, mious=m, ious=io)
+            l, m, io, m64, io64 = run(e)
+            np.savez(part(i), losses=l, mious=m, ious=io, miou64=m64, ious64=io64)
         z = np.load(part(i))
-        L.append(z["losses"]); M.append(z["mious"]); I.append(z["ious"])
+        L.append(z["losses"]); M.append(z["mious"]); I.append(z["ious"]); M64.append(float(z["miou64"])); I64.append(z["ious64"])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_curve_yolov5seg_128.npz"), losses=L[0], mious=M[0],
                         final_ious=I[0], ens_eps=np.array(EPS), ens_mious=np.stack(M), ens_final=np.array([m[-1] for m in M]),
-                        hyp=np.array([S, BS, STEPS, LR, NB, LRF]))
-    print("ensemble final mIoU:", [round(float(m[-1]), 4) for m in M])
+                        ens_final64=np.array(M64), ens_ious64=np.stack(I64), hyp=np.array([S, BS, STEPS, LR, NB, LRF, NVAL]))
+    print("ensemble final mIoU (8 held-out images):", [round(float(m[-1]), 4) for m in M])
+    print("ensemble final mIoU (64 held-out images):", [round(v, 4) for v in M64])
 
 
 if __name__ == "__main__":

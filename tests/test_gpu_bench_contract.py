@@ -24,7 +24,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-6 * d["value"]            # images/s = bs / step time
-    assert d["launch_mode"] in ("eager", "hipgraph")
+    assert d["launch_mode"] in ("eager", "replay", "hipgraph")
     roof = d["roofline"]
     assert roof["bound"] in ("mfma", "hbm") and roof["unit"] in ("TFLOP/s", "GB/s") and roof["peak"] > 0
     assert roof["achieved"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9

@@ -100,18 +100,21 @@ TILED = [
     # bf16: the throughput-mode instantiations of the same tiles (3x3 layers below 200 k pixels: the 128-wide weight-gradient kernel
     # sized to one wave of CTAs; 1x1 layers: the 64x64-tile kernel)
     # (>= 128 output channels and Cin % 64 == 0: the LDS-DMA ring kernel igemm2; otherwise igemm_kernel)
-    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad2_kernel<128>", "")),
+    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
-    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad2_kernel<64>", "")),
-    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "wgrad2_kernel<128>", "")),
+    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
+    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "wgrad3_kernel<128>", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
-    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2_kernel<128,64,8,4,2>", "wgrad2_kernel<64>", "")),
-    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad2_kernel<128>", "")),
+    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2_kernel<128,64,8,4,2>", "wgrad3_kernel<64>", "")),
+    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
     # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
-    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad2_kernel<128>", "")),
+    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3_kernel<128>", "")),
     ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    # 12 -> 64 channels, 3x3 / s1 on a 16-channel-stride input: the thin-input kernel of the space-to-depth stem
+    ("stem_12_64_bf16", "bf16", 4, 12, 64, 3, 1, 320, 320, ("stem_kernel<bf16,16,64>", "", "", "")),
+    ("stem_12_64_small_bf16", "bf16", 2, 12, 64, 3, 1, 48, 64, ("stem_kernel<bf16,16,64>", "", "", "")),
     # ragged: 150 output channels (two channel tiles, the second one partial), odd image size, pixel tail
-    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad2_kernel<128>", "")),
+    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad3_kernel<128>", "")),
 ]
 
 
@@ -149,10 +152,10 @@ def test_pointwise_streaming_kernel_against_oracle(case):
     _check(got, ref, mode, tag)
 
 
-@pytest.mark.parametrize("c1,c2,k,expk", [(128, 128, 1, "wgrad2_kernel<128>"), (128, 64, 3, "wgrad2_kernel<64>"),
-                                          (64, 128, 3, "wgrad2_kernel<128>")])
+@pytest.mark.parametrize("c1,c2,k,expk", [(128, 128, 1, "wgrad3_kernel<128>"), (128, 64, 3, "wgrad3_kernel<64>"),
+                                          (64, 128, 3, "wgrad3_kernel<128>")])
 def test_wgrad2_pipelined_kernel_against_oracle(c1, c2, k, expk):
-    """bf16, M = 8*160*160 = 204 800 >= 200 000 pixels: the 128-wide register-pipelined weight-gradient kernel"""
+    """bf16, M = 8*160*160 = 204 800 >= 200 000 pixels: the 128-wide weight-gradient kernel (LDS-DMA feed, wgrad3_kernel)"""
     got, ref, kern = _case("bf16", 8, c1, c2, k, 1, 160, 160)
     assert kern["wgrad"] == expk, kern
     _check(got, ref, "bf16", expk)
@@ -241,7 +244,7 @@ def test_parity_mode_weight_gradient_is_bitwise_reproducible():
         b, _r, _kb = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
     finally:
         config.set_deterministic(None)
-    assert ka["wgrad"].startswith("wgrad2_kernel")
+    assert ka["wgrad"].startswith("wgrad3_kernel")
     assert torch.equal(a["dw"], b["dw"])
     c, _r, _kc = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
     assert rel_err(c["dw"], a["dw"]) < 1e-4
@@ -321,3 +324,23 @@ def test_bn_replica_sums_in_blocks_against_the_deterministic_path():
     finally:
         config.set_deterministic(None)
         ydl.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 128, 1, 1, 160), (8, 128, 64, 3, 1, 160), (4, 64, 128, 3, 2, 320), (16, 256, 512, 3, 2, 80),
+                                   (3, 64, 152, 3, 1, 83)])
+def test_wgrad_lds_dma_feed_equals_register_staged_kernel(shape):
+    """wgrad3_kernel (operands DMA'd straight into the swizzled LDS image) against wgrad2_kernel (global -> registers -> ds_write):
+    same tiles, same stage order, same MFMA chains — in the deterministic slab form the two are equal bit for bit, on 256-byte and
+    128-byte dY rows, stride 2, pixel tails and a partial channel tile"""
+    from yolo_dual_amd import _lib as L
+    N, c1, c2, k, s_, H = shape
+    res = []
+    try:
+        for dma in (1, 0):
+            L.debug_set(4, dma)
+            got, _ref, kern = _case("bf16", N, c1, c2, k, s_, H, H, seed=5, deterministic=True)
+            assert kern["wgrad"].startswith("wgrad3_kernel" if dma else "wgrad2_kernel"), kern
+            res.append(got["dw"])
+    finally:
+        L.debug_set(4, 1)
+    assert torch.equal(res[0], res[1]), rel_err(res[0], res[1])

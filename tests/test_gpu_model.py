@@ -173,9 +173,11 @@ def test_wgrad_transposed_read_matches_scalar_read(shape):
     N, C1, C2, H, W = shape
     import yolo_dual_amd as ydl
     from yolo_dual_amd import _lib as L
+    from yolo_dual_amd import config
     ydl.set_compute_dtype("bf16")
     torch.manual_seed(0)
     res = []
+    config.set_bn_sums(False)        # both runs see bit-identical dy (the atomically added BN sums differ in their last bits run to run)
     for tr in (1, 0):
         L.debug_set(0, tr)
         m = ydl.Conv(C1, C2, 3, 1).cuda().train()
@@ -187,6 +189,7 @@ def test_wgrad_transposed_read_matches_scalar_read(shape):
         out.square().sum().backward()
         res.append(m.conv.weight.grad.detach().clone())
     L.debug_set(0, 1)
+    config.set_bn_sums(True)
     assert rel_err(res[0].cpu(), res[1].cpu()) < 1e-4       # same products, different split-K / atomic order only
 
 
@@ -253,6 +256,11 @@ def test_commuted_concat_conv_matches_materialised_concat(mode):
     ydl.set_compute_dtype(mode)
     cfg = _cfg("yolov5_seg.yaml", {"C3_DCN": "C3"})
     res = []
+    # the deterministic forms on both sides, so that the backbone (identical in the two arms) contributes nothing and the difference
+    # is the head algebra alone: throughput mode's atomically added BN sums differ in their last bits from run to run, which at
+    # this toy size (2 x 128 x 128: BatchNorms over 32 values) already moves the early layers' bf16 gradients by 20 % between two
+    # runs of the SAME arm
+    config.set_deterministic(True)
     for on in (True, False):
         config.set_commute_concat(on)
         try:
@@ -277,6 +285,7 @@ def test_commuted_concat_conv_matches_materialised_concat(mode):
                         {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if "running" in k}))
         finally:
             config.set_commute_concat(True)
+    config.set_deterministic(None)
     (o1, l1, g1, r1), (o0, l0, g0, r0) = res
     assert sorted(g1) == sorted(g0)                       # same dead-parameter set
     to, tg = (1e-5, 2e-4) if mode == "f32" else (3e-2, 0.15)
@@ -378,8 +387,12 @@ def test_full_size_properties():
 def test_graph_capture_matches_eager():
     """the HIP-graph replay of the training step follows the eager trajectory (same kernels, same order)"""
     import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
     from yolo_dual_amd.graph import GraphedTrainStep
     ydl.set_compute_dtype("bf16")
+    # bit-level comparison: the deterministic forms (slab weight gradients, partial-row BN statistics); throughput mode adds
+    # weight gradients and BN sums with f32 atomics, whose arrival order differs from run to run
+    config.set_deterministic(True)
     losses = {}
     for mode in ("eager", "graph"):
         m = ydl.YOLOv5Seg(_cfg("yolov5_seg.yaml", {"C3_DCN": "C3"}))
@@ -413,6 +426,7 @@ def test_graph_capture_matches_eager():
         losses[mode] = rec
     # same kernels on the same data in the same order: the replayed trajectory is the eager one to the last bit of the
     # printed loss (a 2e-2 tolerance here once hid a replay that ran with broken cross-stream ordering)
+    config.set_deterministic(None)
     for a, b in zip(losses["eager"][2:], losses["graph"][2:]):
         assert abs(a - b) <= 1e-6 * abs(a), (losses)
 

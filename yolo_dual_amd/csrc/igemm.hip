@@ -1127,6 +1127,158 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Thin-input 3x3 convolution: the stem after its space-to-depth rewrite (16 stored input channels -> 64 output channels,
+// stride 1, pad 1; BASELINE config 2: 16 x 320 x 320 pixels).  K = 9 taps x 16 channels = 144: with 64-deep K-steps the tiled
+// kernel spends its time on 16-byte-per-row gathers through LDS for 2.25 K-steps of work and runs at 1.9 TB/s of a layer whose
+// bytes (52 MB in, 210 MB out) are all it costs.  Here, like the point-wise kernel:
+//   * weight-stationary IN REGISTERS: a lane's MFMA A fragments of all 4 channel tiles x 5 K-slices (80 VGPRs) are loaded once;
+//   * activations go global -> registers in the MFMA B layout: K-slice s = taps 2s and 2s+1, a lane (pixel = lane & 15,
+//     k-group = lane >> 4) reads the 16-byte half (k-group & 1) of tap 2s + (k-group >> 1) at its pixel — 16 pixels x 32 bytes
+//     contiguous per tap, range-checked buffer loads return zeros for the padding taps; the next tile's five loads are in
+//     flight while the current tile's 20 MFMAs issue; no LDS, no barrier in the main loop;
+//   * a wave owns 16 consecutive pixels of one image row per step (Wo % 16 == 0), output through a per-wave LDS transpose
+//     into whole 128-byte NHWC rows, per-lane (sum, sum of squares) for the BN statistics, reduced once per CTA.
+// ------------------------------------------------------------------------------------------------------
+struct StemArgs {
+    const bf16_t* X; const bf16_t* W; bf16_t* Y; float* stats;
+    int H, Wd, ldc, M, block_m, stats_ld, stats_atomic;
+    unsigned bytesX;
+};
+struct StemPlan { bool ok; int block_m, grid_m; };
+static int g_stem_enabled = 1;
+static StemPlan stem_plan(int M, int Wo) {
+    StemPlan pl{};
+    static const int env = getenv("YDL_STEM") ? atoi(getenv("YDL_STEM")) : 1;
+    pl.ok = g_stem_enabled && env && Wo % 16 == 0 && M >= 4096;
+    if (!pl.ok) return pl;
+    const int slots = ydl_device_cus() * 3;
+    pl.block_m = round_up((M + slots - 1) / slots, 64);
+    pl.grid_m = (M + pl.block_m - 1) / pl.block_m;
+    return pl;
+}
+
+#define STEM_ROWB 144       // LDS transpose rows: 128 data bytes + 16 (a wave's 8-byte writes of 16 rows spread over the banks)
+__global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 16 * STEM_ROWB];
+    __shared__ float red[4 * 64 * 2];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int chunk = lgrp & 1, tsel = lgrp >> 1;
+    // weights: A fragment (ct, s) = w[ct*16 + lrow][tap 2s + tsel][chunk*8 .. +8]; tap 9 does not exist (zeros)
+    uint4 af[4][5];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) {
+            const int tap = 2 * sl + tsel;
+            af[ct][sl] = tap < 9 ? *(const uint4*)(p.W + ((size_t)(ct * 16 + lrow) * 9 + tap) * 16 + chunk * 8) : make_uint4(0, 0, 0, 0);
+        }
+    int dh[5], dw[5];
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+        const int tap = 2 * sl + tsel;
+        dh[sl] = tap < 9 ? tap / 3 - 1 : 100000;         // the missing tap is always out of range
+        dw[sl] = tap < 9 ? tap % 3 - 1 : 0;
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.bytesX, 0x00020000);
+    const int HW = p.H * p.Wd;
+    const int m_begin = blockIdx.x * p.block_m;
+    const int m_end = min(p.M, m_begin + p.block_m);
+    float s1[16], s2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+
+    auto load_tile = [&](int m0, uint4 (&b)[5]) {
+        // m0: first pixel of a 16-pixel tile inside one image row (wave-uniform)
+        const int n = m0 / HW;
+        const int rem = m0 - n * HW;
+        const int h = rem / p.Wd;
+        const int w = rem - h * p.Wd + lrow;
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) {
+            const int ih = h + dh[sl], iw = w + dw[sl];
+            const bool ok = m0 < m_end && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd;
+            const unsigned off = ok ? (unsigned)(((n * p.H + ih) * p.Wd + iw) * 32 + chunk * 16) : 0xFFFFFFFFu;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            b[sl] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    unsigned char* my_stage = stage + wave * (16 * STEM_ROWB);
+    uint4 bc[5], bn[5];
+    int m0 = m_begin + wave * 16;
+    load_tile(m0, bc);
+    for (; m0 < m_end; m0 += 64) {
+        load_tile(m0 + 64, bn);                      // (beyond m_end: every lane out of range)
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) Mma<bf16_t>::run(af[ct][sl], bc[sl], acc[ct]);
+        // lane: pixel m0 + lrow, channels ct*16 + lgrp*4 + e
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[ct][e];
+                s1[ct * 4 + e] += v;
+                s2[ct * 4 + e] += v * v;
+            }
+            uint2 u;
+            u.x = (uint32_t)f2bf(acc[ct][0]) | ((uint32_t)f2bf(acc[ct][1]) << 16);
+            u.y = (uint32_t)f2bf(acc[ct][2]) | ((uint32_t)f2bf(acc[ct][3]) << 16);
+            *(uint2*)(my_stage + lrow * STEM_ROWB + (ct * 16 + lgrp * 4) * 2) = u;
+        }
+        // (LDS instructions of one wave execute in order: the reads below see the writes above)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slot = lane + 64 * i;
+            const int row = slot >> 3, ch = slot & 7;
+            const uint4 v = *(const uint4*)(my_stage + row * STEM_ROWB + ch * 16);
+            *(uint4*)(p.Y + (size_t)(m0 + row) * p.ldc + ch * 8) = v;
+        }
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) bc[sl] = bn[sl];
+    }
+    // statistics: sum over the 16 pixel lanes (transposing butterfly), then over the CTA's 4 waves
+    row_reduce<16>(s1, lrow);
+    row_reduce<16>(s2, lrow);
+    {
+        const int ch = (lrow >> 2) * 16 + lgrp * 4 + (lrow & 3);     // value index lrow = ct*4 + e of this lane group
+        red[(wave * 64 + ch) * 2] = s1[0];
+        red[(wave * 64 + ch) * 2 + 1] = s2[0];
+    }
+    __syncthreads();
+    if (p.stats != nullptr && t < 64) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[(w * 64 + t) * 2]; b += red[(w * 64 + t) * 2 + 1]; }
+        if (p.stats_atomic) {
+            float* dst = p.stats + (size_t)(blockIdx.x & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
+            atomicAdd(dst + t, a);
+            atomicAdd(dst + p.stats_ld + t, b);
+        } else {
+            const float n = (float)(m_end - m_begin);
+            float* dst = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld;
+            dst[t] = a;
+            dst[p.stats_ld + t] = fmaxf(b - a * a / n, 0.f);          // (sum, M2) of this block's pixels
+        }
+    }
+}
+
+static bool args_stem(const IgemmArgs& a) {
+    if (!(a.ntaps == 9 && a.Ttot == 9 && a.Kc == 16 && a.lda == 16 && a.Cout == 64 && a.Cst == 64 && a.in_mul == 1 && a.out_mul == 1 &&
+          a.ncls <= 1 && a.Hi == a.Ho && a.Wi == a.Wo && a.Hg == a.Ho && a.Wg == a.Wo && a.out_h0 == 0 && a.out_w0 == 0 &&
+          a.accumulate == 0 && a.ldb_bytes == 9u * 16u * 2u))
+        return false;
+    for (int tp = 0; tp < 9; ++tp)
+        if (a.dh[tp] != tp / 3 - 1 || a.dw[tp] != tp % 3 - 1 || a.wt[tp] != tp) return false;
+    return true;
+}
+
 struct PwPlan { bool ok; int RB, CT, WN, NW, block_m, grid_m; size_t smem, tstage; };
 static int g_pw_enabled = 1;
 static int g_dgrad_merge = 1;
@@ -1327,6 +1479,22 @@ static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int 
 
 template <typename T>
 static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid_m_out = nullptr, int force_bm = 0) {
+    if constexpr (sizeof(T) == 2) {
+        if (fam == 0 && !force_bm && args_stem(a)) {
+            const StemPlan sp = stem_plan(a.M, a.Wo);
+            if (sp.ok) {
+                StemArgs q{};
+                q.X = (const bf16_t*)a.A; q.W = (const bf16_t*)a.B; q.Y = (bf16_t*)a.C; q.stats = a.stats;
+                q.H = a.Hi; q.Wd = a.Wi; q.ldc = a.ldc; q.M = a.M; q.block_m = sp.block_m; q.stats_ld = a.stats_ld;
+                q.stats_atomic = a.stats_atomic; q.bytesX = a.bytesA;
+                if (grid_m_out) *grid_m_out = sp.grid_m;
+                ydl_note_kernel(fam, "stem_kernel<bf16,16,64>");
+                stem_kernel<<<sp.grid_m, 256, 0, st>>>(q);
+                YDL_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
     {
         const PwPlan pl = pw_plan(a.M, a.Kc, a.Cout, a.Cst, (int)sizeof(T), args_pointwise(a));
         if (pl.ok && !force_bm) {
@@ -1402,6 +1570,11 @@ static int check_geom(const ydl_conv_geom* g, int dtype) {
 static void fwd_blocks(const ydl_conv_geom* g, int dtype, int* grid_m, int* block_m) {
     int M = g->N * g->Ho * g->Wo;
     int Cst = round_up(g->Cout, 8) <= g->ldy ? round_up(g->Cout, 8) : g->Cout;
+    if (dtype == YDL_BF16 && g->k == 3 && g->s == 1 && g->p == 1 && round_up(g->Cin, 8) == 16 && g->ldx == 16 && g->Cout == 64 && Cst == 64 &&
+        g->ldw == 0) {
+        const StemPlan sp = stem_plan(M, g->Wo);          // the thin-input kernel (same conditions as args_stem)
+        if (sp.ok) { *grid_m = sp.grid_m; *block_m = sp.block_m; return; }
+    }
     const PwPlan pl = pw_plan(M, round_up(g->Cin, 8), g->Cout, Cst, esize(dtype), g->k == 1 && g->s == 1 && g->p == 0);
     if (pl.ok) { *grid_m = pl.grid_m; *block_m = pl.block_m; return; }
     TileCfg c = pick_cfg(M, Cst, g->k * g->k * (round_up(g->Cin, 8) / (16 / esize(dtype))), dtype == YDL_BF16,
@@ -1758,6 +1931,7 @@ struct Wgrad2Args {
     int njt, nct;
     int ldw;                              // dW row stride (floats)
     float* slab;                          // deterministic mode: [splits][Cout][ntaps*Kc] partial sums, else NULL
+    int dbg;                              // timing experiments only (YDL_WG3_DBG): 1 no DMA, 2 no epilogue, 3 no MFMA/LDS reads
 };
 
 template <int TCO>
@@ -1899,11 +2073,204 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const Wgrad2Args p) {
         }
 }
 
+// ======================================================================================================
+// wgrad3: the same tile (TCO output channels x 128 flattened-K columns, 64 pixels per stage, transposed LDS reads) fed by
+// LDS-DMA like igemm2 — `buffer_load_dwordx4 ... lds` straight into the LDS image, no staging registers and no ds_write pass.
+// Why: the register-staged kernel above is bound by its LDS WRITES (ds_write_b128 moves address + data VGPRs at ~79 B/clk/CU,
+// 335 LDS cycles against 128 MFMA cycles per stage in the 64x64-tile kernel, profiles/r2_pmc_wgrad_*.txt), not by MFMA issue.
+// A wave-instruction writes 1 KiB = (wave-uniform M0 base) + lane*16: exactly the row-major images the register kernel
+// builds (X: 4 rows x 256 B per instruction; dY: 4 rows x 256 B for TCO = 128, 8 rows x 128 B for TCO = 64), so the thread ->
+// (row, 16-byte slot) map is unchanged and the XOR swizzle of the 32-byte blocks moves to the per-lane SOURCE address: the
+// lane at slot qs of row r fetches the logical chunk (((qs >> 1) ^ f(r)) << 1) | (qs & 1).  f depends on row bits that the
+// per-pass row stride (16 / 32 rows) leaves alone, so a thread's (tap, channel) stays fixed for the whole kernel.
+// Pipeline: two LDS stages; per stage  s_waitcnt vmcnt(0) + s_barrier (stage s landed everywhere, everyone is done with the
+// buffer stage s+1 goes to) -> issue the DMAs of stage s+1 -> MFMAs of stage s.  Rows beyond the pixel range and padding taps
+// are out-of-range buffer offsets: the DMA writes zeros.  64 KB (TCO 128) / 48 KB (TCO 64) of LDS: two / three CTAs per CU.
+// ======================================================================================================
+template <int ROWB_>
+__device__ __forceinline__ int w3f(int row) {
+    // XOR applied to the 32-byte block index of a row: 256-byte rows (8 blocks) use (row & 3) | bit3 << 2 as wgrad2 does;
+    // 128-byte rows (4 blocks, two rows per 256-byte bank line) use bit1 | bit3 << 1 — rows {0,2,8,10} / {1,3,9,11} of a
+    // transposed read's half-wave then cover the 64 banks exactly once
+    return ROWB_ == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+template <int ROWB_>
+__device__ __forceinline__ int w3sw(int row, int colbyte) {
+    return row * ROWB_ + ((((colbyte >> 5) ^ w3f<ROWB_>(row)) << 5) | (colbyte & 31));
+}
+
+template <int TCO, int SP, int S>
+__global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wgrad2Args p) {
+    // SP = pixels per stage (32 or 64), S = stages of the LDS ring: S-1 stages are in flight while one is multiplied.  The loads are
+    // latency-bound (timing experiment without MFMAs: 90 % of the kernel's time, 10 TB/s of L2->LDS traffic at ~64 KB in flight per
+    // CU), so the ring is cut into more, smaller stages rather than made bigger.
+    constexpr int WCO = TCO / 64;              // waves along cout
+    constexpr int WJ = 4 / WCO;                // waves along j
+    constexpr int JW = 128 / WJ;               // j columns per wave
+    constexpr int NA = 4;                      // cout tiles per wave (64 / 16)
+    constexpr int NB = JW / 16;                // j tiles per wave
+    constexpr int YCH = TCO / 8;               // 16-byte chunks per dY tile row
+    constexpr int YROWB = TCO * 2;             // dY tile row bytes (128 or 256): the DMA image has no gaps
+    constexpr int YRP = 256 / YCH;             // dY rows per pass of the CTA
+    constexpr int YR = SP / YRP;               // dY DMAs per thread per stage
+    constexpr int XR = SP / 16;                // X DMAs per thread per stage
+    constexpr int L = YR + XR;
+    constexpr int YBYTES = SP * YROWB, XBYTES = SP * 256, STAGE = YBYTES + XBYTES;
+    static_assert(YR >= 1 && SP % 32 == 0 && S >= 2, "stage geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wave / WJ, wj = wave % WJ;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = tile % p.njt, ct = (tile / p.njt) % p.nct, zt = tile / (p.njt * p.nct);
+    const int cpt = p.Kc / 8;
+    const int nchunks = p.ntaps * cpt;
+    // X image: 16 slots per row, 16 rows per pass; this thread's slot xq of rows xr + 16 i holds logical chunk xlog
+    const int xq = t & 15, xr = t >> 4;
+    const int xlog = (((xq >> 1) ^ w3f<256>(xr)) << 1) | (xq & 1);
+    const int Q = jt * 16 + xlog;
+    const bool qv = Q < nchunks;
+    const int tap = qv ? Q / cpt : 0;
+    const int cc = (Q - tap * cpt) * 8;
+    const int dh = tap / p.k - p.p, dw = tap % p.k - p.p;
+    // dY image: YCH slots per row, YRP rows per pass
+    const int yq = t % YCH, yr = t / YCH;
+    const int ylog = (((yq >> 1) ^ w3f<YROWB>(yr)) << 1) | (yq & 1);
+    const int co_chunk = ct * TCO + ylog * 8;
+    const bool yv = co_chunk < p.Cout;
+    const int pbeg = zt * p.chunk;
+    const int pend = min(p.M, pbeg + p.chunk);
+    const int HoWo = p.Ho * p.Wo;
+    u32x4 rsX, rsY;
+    {
+        const unsigned long long px = (unsigned long long)p.X, py = (unsigned long long)p.dY;
+        rsX = u32x4{(unsigned)px, (unsigned)(px >> 32) & 0xffffu, p.bytesX, 0x00020000u};
+        rsY = u32x4{(unsigned)py, (unsigned)(py >> 32) & 0xffffu, p.bytesY, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_y = lds0 + (unsigned)wave * 1024u;                     // a wave's 1 KiB of each dY pass
+    const unsigned wave_x = lds0 + (unsigned)YBYTES + (unsigned)wave * 1024u;  // ... and of each X pass
+
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int p0, int buf) {
+        const unsigned base = (unsigned)buf * (unsigned)STAGE;
+        if (p.dbg == 1) return;
+#pragma unroll
+        for (int i = 0; i < YR; ++i) {
+            const int m = p0 + yr + YRP * i;
+            const unsigned off = (yv && m < pend) ? (unsigned)(m * p.ldy + co_chunk) * 2u : 0xFFFFFFFFu;
+            lds_dma16(rsY, wave_y + base + (unsigned)i * 4096u, off);
+        }
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int m = p0 + xr + 16 * i;
+            const unsigned n = fastdiv40((unsigned)m, p.magicHW);
+            const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+            const unsigned ho = fastdiv40(rem, p.magicW);
+            const unsigned wo = rem - ho * (unsigned)p.Wo;
+            const int ih = (int)ho * p.s + dh, iw = (int)wo * p.s + dw;
+            const bool ok = qv && m < pend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            const unsigned off = ok ? (unsigned)(((int)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * 2u : 0xFFFFFFFFu;
+            lds_dma16(rsX, wave_x + base + (unsigned)i * 4096u, off);
+        }
+    };
+    const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    auto compute = [&](int cur) {
+        const unsigned char* by = smem + cur * STAGE;
+        const unsigned char* bx = by + YBYTES;
+#pragma unroll
+        for (int ks = 0; ks < SP / 32; ++ks) {
+            uint4 af[NA], bfv[NB];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int row = ks * 32 + g * 8 + lq;
+                const unsigned char* lo_p = by + w3sw<YROWB>(row, (wi * 64 + a * 16 + lp * 4) * 2);
+                const unsigned char* hi_p = by + w3sw<YROWB>(row + 4, (wi * 64 + a * 16 + lp * 4) * 2);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                af[a] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = ks * 32 + g * 8 + lq;
+                const unsigned char* lo_p = bx + w3sw<256>(row, (wj * JW + b * 16 + lp * 4) * 2);
+                const unsigned char* hi_p = bx + w3sw<256>(row + 4, (wj * JW + b * 16 + lp * 4) * 2);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                bfv[b] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) Mma<bf16_t>::run(af[a], bfv[b], acc[a][b]);
+        }
+    };
+
+    // ring: stage k of this CTA lives in buffer k % S.  Per stage: wait until only the S-2 youngest stages' DMAs are outstanding
+    // (stage k has landed), barrier (everyone's have; every wave is done with stage k-1), issue stage k+S-1 into the buffer stage
+    // k-1 occupied, multiply stage k.  Stages beyond pend are all-out-of-range DMAs (zeros nobody multiplies): the vmcnt
+    // arithmetic stays uniform.
+#pragma unroll
+    for (int u = 0; u < S - 1; ++u) issue(pbeg + u * SP, u);
+    int buf = 0, nxt = S - 1;
+    for (int p0 = pbeg; p0 < pend; p0 += SP) {
+        wait_vm_barrier<L * (S - 2)>();
+        issue(p0 + (S - 1) * SP, nxt);
+        if (p.dbg != 3) compute(buf);
+        buf = buf + 1 == S ? 0 : buf + 1;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
+    }
+    wait_vm_barrier<0>();                          // the trailing DMAs land before the CTA (and its LDS allocation) goes away
+    if (p.dbg == 2) {
+        float sink = 0.f;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) sink += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (sink == 123.456f) p.dW[0] = sink;
+        return;
+    }
+    const size_t wrow = (size_t)p.ntaps * p.Kc;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            int j = jt * 128 + wj * JW + b * 16 + (lane & 15);
+            if (j < (int)wrow) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int co = ct * TCO + wi * 64 + a * 16 + (lane >> 4) * 4 + e;
+                    if (co < p.Cout) {
+                        if (p.slab) p.slab[((size_t)zt * p.Cout + co) * wrow + j] = acc[a][b][e];
+                        else atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
+                    }
+                }
+            }
+        }
+}
+
+template <int TCO, int SP, int S>
+static int launch_wgrad3(const Wgrad2Args& a, dim3 grid, hipStream_t st) {
+    const size_t smem = (size_t)S * (SP * (TCO * 2) + SP * 256);
+    YDL_SET_MAX_LDS((wgrad3_kernel<TCO, SP, S>), smem);
+    wgrad3_kernel<TCO, SP, S><<<grid, 256, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- wgrad launch plan: a pure function of (geometry, dtype, debug knobs); the workspace query and the launch share it
 struct WgradPlan { int kind;     // 0: wgrad_kernel<float>, 1: wgrad_kernel<bf16,tr>, 2: wgrad_kernel<bf16,scalar>, 3: wgrad2<64>, 4: wgrad2<128>
                    int jtiles, ctiles, splits, chunk; };
 
 static int g_wgrad_tr = 1;
+static int g_wgrad_dma = 1;      // 128-wide weight-gradient kernel: 1 = LDS-DMA feed (wgrad3_kernel), 0 = register-staged (wgrad2_kernel)
 
 static WgradPlan wgrad_plan(const ydl_conv_geom* g, int dtype) {
     WgradPlan pl{};
@@ -2004,6 +2371,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 2 = strided dgrad: 1 (default) all output-parity classes in one launch, 0 one launch per class
 //              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
 //              key 3 = bf16 LDS-DMA ring kernel (igemm2) for the MFMA-bound layers: 1 (default) on, 0 off (igemm_kernel everywhere)
+//              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
+//              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
 // Process-wide and test-only: they change launch geometry, so callers that cache ydl_conv_fwd_grid_m/... must drop the cache
 // after a change (yolo_dual_amd._lib.debug_set does).
 extern "C" void ydl_debug_set(int key, int val) {
@@ -2011,6 +2380,8 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 1) g_pw_enabled = val;
     if (key == 2) g_dgrad_merge = val;
     if (key == 3) g_ring_enabled = val;
+    if (key == 4) g_wgrad_dma = val;
+    if (key == 5) g_stem_enabled = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
@@ -2046,13 +2417,27 @@ static int conv_wgrad_impl(const ydl_conv_geom* g, int dtype, const void* x, con
         a.ldw = ldw; a.M = M; a.chunk = pl.chunk;
         a.bytesX = (unsigned)bx; a.bytesY = (unsigned)by; a.magicW = magicW; a.magicHW = magicHW;
         a.njt = pl.jtiles; a.nct = pl.ctiles; a.slab = slab;
-        const size_t smem = 4 * 64 * W2_ROWB;
-        YDL_SET_MAX_LDS((wgrad2_kernel<128>), smem);
-        YDL_SET_MAX_LDS((wgrad2_kernel<64>), smem);
-        ydl_note_kernel(2, pl.kind == 4 ? "wgrad2_kernel<128>" : "wgrad2_kernel<64>");
-        if (pl.kind == 4) wgrad2_kernel<128><<<grid, 256, smem, st>>>(a);
-        else wgrad2_kernel<64><<<grid, 256, smem, st>>>(a);
-        YDL_LAUNCH_CHECK();
+        static const int w3dbg = getenv("YDL_WG3_DBG") ? atoi(getenv("YDL_WG3_DBG")) : 0;
+        a.dbg = w3dbg;
+        static const int dma_env = getenv("YDL_WG3") ? atoi(getenv("YDL_WG3")) : 1;
+        if (g_wgrad_dma && dma_env) {
+            // ring shape (YDL_WG3_CFG, tuning): 0 = 64-pixel stages x 2, 1 = 32-pixel stages x 4 (same LDS, three stages in flight),
+            // 2 = 64-pixel stages x 3 (one CTA per CU for TCO = 128)
+            static const int cfg = getenv("YDL_WG3_CFG") ? atoi(getenv("YDL_WG3_CFG")) : 1;
+            ydl_note_kernel(2, pl.kind == 4 ? "wgrad3_kernel<128>" : "wgrad3_kernel<64>");
+            int e = 0;
+            if (pl.kind == 4) e = cfg == 0 ? launch_wgrad3<128, 64, 2>(a, grid, st) : (cfg == 2 ? launch_wgrad3<128, 64, 3>(a, grid, st) : launch_wgrad3<128, 32, 4>(a, grid, st));
+            else e = cfg == 0 ? launch_wgrad3<64, 64, 2>(a, grid, st) : (cfg == 2 ? launch_wgrad3<64, 64, 3>(a, grid, st) : launch_wgrad3<64, 32, 4>(a, grid, st));
+            if (e) return e;
+        } else {
+            const size_t smem = 4 * 64 * W2_ROWB;
+            YDL_SET_MAX_LDS((wgrad2_kernel<128>), smem);
+            YDL_SET_MAX_LDS((wgrad2_kernel<64>), smem);
+            ydl_note_kernel(2, pl.kind == 4 ? "wgrad2_kernel<128>" : "wgrad2_kernel<64>");
+            if (pl.kind == 4) wgrad2_kernel<128><<<grid, 256, smem, st>>>(a);
+            else wgrad2_kernel<64><<<grid, 256, smem, st>>>(a);
+            YDL_LAUNCH_CHECK();
+        }
     } else {
         WgradArgs a{};
         a.X = x; a.dY = dy; a.dW = dw;

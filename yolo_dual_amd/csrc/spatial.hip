@@ -641,15 +641,28 @@ extern "C" int ydl_channel_dot(int dtype, const void* a, int lda, const void* b,
 // ------------------------------------------------------------------------------------------------------
 // zero fills (the taped region issues no ATen kernel; these are recordable entry points like every other launch)
 // ------------------------------------------------------------------------------------------------------
+// a plain kernel, not hipMemsetAsync: a memset becomes a memset NODE under HIP-graph capture, and a chain of captured graph
+// segments with memset nodes in it replayed with wrong contents on ROCm 7.2 (tests/test_gpu_dp.py, segmented capture); as a kernel
+// the fill is ordered like every other launch, eagerly, in a graph and in a launch list
+__global__ __launch_bounds__(256) void fill_zero_kernel(unsigned char* __restrict__ dst, long long bytes) {
+    const long long head = (16 - ((uintptr_t)dst & 15)) & 15;        // bytes up to the first 16-byte boundary
+    const long long h = head < bytes ? head : bytes;
+    const long long nvec = (bytes - h) >> 4;
+    uint4* v = (uint4*)(dst + h);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x)
+        v[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0) {
+        for (long long i = threadIdx.x; i < h; i += blockDim.x) dst[i] = 0;
+        const long long tail0 = h + (nvec << 4);
+        for (long long i = tail0 + threadIdx.x; i < bytes; i += blockDim.x) dst[i] = 0;
+    }
+}
 extern "C" int ydl_fill_zero(void* dst, int64_t bytes, void* stream) {
     YDL_CHECK(dst != nullptr || bytes == 0, "null destination");
     YDL_CHECK(bytes >= 0, "negative size");
     if (bytes == 0) return 0;
-    hipError_t e = hipMemsetAsync(dst, 0, (size_t)bytes, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        ydl_set_error(std::string("ydl_fill_zero: hipMemsetAsync failed: ") + hipGetErrorString(e));
-        return 2;
-    }
+    fill_zero_kernel<<<sgrid((bytes + 15) / 16), 256, 0, (hipStream_t)stream>>>((unsigned char*)dst, (long long)bytes);
+    YDL_LAUNCH_CHECK();
     return 0;
 }
 template <typename T>

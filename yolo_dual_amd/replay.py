@@ -112,9 +112,12 @@ class Recorder:
     def size(self) -> int:
         return int(self.lib.ydl_replay_size(self.h))
 
-    def run(self, first: int, last: int) -> None:
-        arr = (ctypes.c_void_p * len(self.handles))(*[ctypes.c_void_p(h) for h in self.handles])
-        L.check(self.lib.ydl_replay_run(self.h, first, last, arr, len(self.handles)), "ydl_replay_run")
+    def run(self, first: int, last: int, handles=None) -> None:
+        """re-issue operations [first, last) on the recorded streams, or on ``handles`` (one raw stream per slot: the list only names
+        slots, any set of distinct streams preserves its dependencies)"""
+        hs = self.handles if handles is None else handles
+        arr = (ctypes.c_void_p * len(hs))(*[ctypes.c_void_p(h) for h in hs])
+        L.check(self.lib.ydl_replay_run(self.h, first, last, arr, len(hs)), "ydl_replay_run")
 
 
 class ReplayedTrainStep:
@@ -124,7 +127,8 @@ class ReplayedTrainStep:
     With a data-parallel wrapper (``dp``) the list is cut where the eager step launches a gradient bucket: a replay alternates
     "segment, bucket collective" exactly like eager mode, collectives overlapping the remaining backward segments."""
 
-    def __init__(self, model, criterion, optimizer: FlatSGDEMA, imgs: torch.Tensor, targets: torch.Tensor, dp=None, warmup: int = 2):
+    def __init__(self, model, criterion, optimizer: FlatSGDEMA, imgs: torch.Tensor, targets: torch.Tensor, dp=None, warmup: int = 2,
+                 prioritize: bool = False):
         if getattr(criterion, "sync", False):
             raise ValueError("a launch list needs a loss that does not sync: SegmentationLoss(..., sync=False)")
         self.model, self.criterion, self.opt, self.dp = model, criterion, optimizer, dp
@@ -170,6 +174,15 @@ class ReplayedTrainStep:
             finally:
                 L.set_recorder(None)
         self._n_all = self.rec.size()
+        # optional: replay slot 0 (the main chain: forward, BN backward, input gradients, optimizer) on a HIGH-priority stream and
+        # the other slots (weight gradients, dead head branch) on low-priority ones, so that the hardware scheduler hands CUs to
+        # the critical path first and the side work fills what is left
+        self._handles = None
+        if prioritize and not self.multi:
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            self._prio_streams = [torch.cuda.Stream(priority=hi)] + [torch.cuda.Stream(priority=lo) for _ in self.rec.handles[1:]]
+            self._handles = [st.cuda_stream for st in self._prio_streams]
+            self.main = self._prio_streams[0]
         self._nbt_per_replay = [bn._nbt_pending - a for bn, a in zip(self._bns, nbt0)]
         torch.cuda.synchronize()
 
@@ -249,8 +262,10 @@ class ReplayedTrainStep:
             self.opt.prepare_step(scale)
             self.rec.run(self._n_fb, self._n_all)
         else:
-            self.opt.prepare_step(scale)               # H2D of {lr, momentum, wd, scale, EMA decay}: ahead of the list on the same stream
-            self.rec.run(0, self._n_all)
+            self.opt.prepare_step(scale)               # H2D of {lr, momentum, wd, scale, EMA decay}: ahead of the list (the main slot waits for it)
+            if self._handles is not None:
+                self.main.wait_stream(cur)
+            self.rec.run(0, self._n_all, self._handles)
         for bn, k in zip(self._bns, self._nbt_per_replay):
             bn._nbt_pending += k
         config.bump_weight_epoch()

@@ -36,6 +36,7 @@ def _stream() -> ctypes.c_void_p:
 
 
 _SIDE = {}
+_NO_SLAB = __import__("os").environ.get("YDL_SLAB", "1") == "0"
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -210,6 +211,8 @@ class Tape:
         """``nfloats`` f32 zeros (16-byte aligned) from the region's slab: ONE memset per slab instead of one per accumulator row.
         A slab is cleared when it is created, before any kernel that adds into it is enqueued; rows are handed out once."""
         n = round_up(nfloats, 4)
+        if _NO_SLAB:                      # debugging switch: every row its own buffer and memset
+            return zero_(torch.empty(nfloats, dtype=torch.float32, device=self.device))
         self._slab_total += n
         if self._slab is None or self._slab_off + n > self._slab.numel():
             cap = max(1 << 18, self._slab_hint, 2 * n, 2 * (self._slab.numel() if self._slab is not None else 0))
@@ -218,10 +221,14 @@ class Tape:
             # the memset went to the CURRENT stream; rows of this slab may be used on the region's other stream too (dead head
             # branch, deferred work): order it behind the memset.  Normally the slab is sized from the previous step's need and
             # created once, by the first layer, before any fork.
+            # (Only when this region has forked the side stream already: waiting on a stream that is not part of the step
+            #  would pull it into a HIP-graph capture and leave it unjoined.)
             cur = torch.cuda.current_stream()
-            for other in (self._main, _SIDE.get(torch.cuda.current_device())):
-                if other is not None and other.cuda_stream != cur.cuda_stream:
-                    stream_wait(other, cur)
+            side = _SIDE.get(torch.cuda.current_device())
+            if side is not None and (self._side_used or getattr(self, "_side_fwd", False)):
+                for other in (self._main, side):
+                    if other is not None and other.cuda_stream != cur.cuda_stream:
+                        stream_wait(other, cur)
         out = self._slab[self._slab_off:self._slab_off + nfloats]
         self._slab_off += n
         return out
