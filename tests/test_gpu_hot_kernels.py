@@ -163,7 +163,7 @@ def test_wgrad2_pipelined_kernel_against_oracle(c1, c2, k, expk):
 
 def test_bf16_dgrad_accumulate_variants_against_oracle():
     """the ACCUMULATING input-gradient launches of throughput mode (second writer of a shared gradient: read-modify-write
-    epilogue, non-transposed "direct" stores in the point-wise kernel) against the CPU oracle: an un-fused script C3 — cv1 and cv2
+    epilogue of the ring kernel, 16-byte read-modify-write rows of the point-wise kernel) against the CPU oracle: an un-fused script C3 — cv1 and cv2
     read the same x, so cv1's dgrad (the later one in backward order) adds into what cv2's wrote; 128 channels at 4x160x160
     selects the streaming kernel for the 1x1 layers and the ring kernel for the 3x3"""
     import yolo_dual_amd as ydl
@@ -189,8 +189,9 @@ def test_bf16_dgrad_accumulate_variants_against_oracle():
         (out * gup.cuda()).sum().backward()
         torch.cuda.synchronize()
         last_dgrad = L.last_kernel(1)
-        # cv1's dgrad comes last and adds into what cv3's residual branch and cv2's dgrad wrote: accumulate => direct stores
-        assert last_dgrad.startswith("pw_kernel<bf16,") and last_dgrad.endswith(",direct>"), last_dgrad
+        # cv1's dgrad comes last and adds into what cv3's residual branch and cv2's dgrad wrote: the accumulating launch without
+        # statistics goes through the LDS-transposed 16-byte read-modify-write rows
+        assert last_dgrad.startswith("pw_kernel<bf16,") and last_dgrad.endswith(",ts>"), last_dgrad
         ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
         run = {k: v.clone() for k, v in sd.items()}
         run.update(ps)

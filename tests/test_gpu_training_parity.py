@@ -3,7 +3,7 @@
 1. ``test_training_run_reaches_the_oracle_miou``: a run that actually learns — YOLOv5Seg, 128x128 blobby masks,
    batch 8 cycling over 16 batches, CE + 0.5*Dice, SGD-nesterov with a linearly decaying learning rate, 600 steps — replayed on the HIP path in parity (f32) and
    throughput (bf16) mode against the CPU oracle's committed 4-member ensemble (tests/golden/train_curve_yolov5seg_128.npz,
-   written by oracle/make_train_curve.py): the oracle reaches held-out mIoUs of 0.78-0.90 (val_diceloss.py:37-75 metric,
+   written by oracle/make_train_curve.py): the oracle reaches mIoUs of 0.77-0.87 on 64 held-out images (val_diceloss.py:37-75 metric,
    eval-mode BN); the run is chaotic, so ensembles are compared, not single trajectories.
 2. ``test_short_training_run_tracks_the_oracle``: 24 steps at 96x96 against a live CPU-oracle run, per-step losses.  Parity
    mode is bitwise reproducible (deterministic split-K weight gradients), so its bound is the 2e-3 the test started with."""
@@ -128,8 +128,8 @@ def _blobby128(seed, n, S=128):
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_training_run_reaches_the_oracle_miou(mode):
-    """The learning run is CHAOTIC: adding 1e-6 to the images of one batch moves the CPU oracle's own final mIoU between 0.78 and
-    0.90 (the fixture stores that 4-member ensemble, oracle/make_train_curve.py), and the HIP path behaves the same
+    """The learning run is CHAOTIC: adding 1e-6 to the images of one batch moves the CPU oracle's own final mIoU between 0.77 and
+    0.87 (the fixture stores that 4-member ensemble, oracle/make_train_curve.py), and the HIP path behaves the same
     (tools/chaos_probe.py).  A single-run comparison to +-0.01 therefore cannot be met by the oracle against itself; what is
     asserted instead:
       * identical trajectories before the chaos sets in: the first 10 losses of the unperturbed member match the oracle's
@@ -143,13 +143,19 @@ def test_training_run_reaches_the_oracle_miou(mode):
     fx = np.load(os.path.join(GOLDEN, "train_curve_yolov5seg_128.npz"))
     S_, BS_, STEPS_, LR_, NB_ = (int(fx["hyp"][0]), int(fx["hyp"][1]), int(fx["hyp"][2]), float(fx["hyp"][3]), int(fx["hyp"][4]))
     LRF_ = float(fx["hyp"][5])
-    ref_losses, ref_final = fx["losses"], fx["ens_final"]
+    # final evaluation on 64 held-out images (8 batches, one confusion matrix): the oracle's four members end at 0.870 / 0.833 /
+    # 0.772 / 0.777 there against 0.878 / 0.856 / 0.795 / 0.781 on the first of those batches alone — the 0.1 spread between
+    # members is NOT evaluation noise (an 8x larger validation set moves every member by less than 0.025 and leaves the spread
+    # where it was): it is the training run diverging from a 1e-6 perturbation.  Nothing tighter than the ensemble comparison below
+    # is testable, whatever the size of the validation set.
+    NVAL_ = int(fx["hyp"][6])
+    ref_losses, ref_final = fx["losses"], fx["ens_final64"]
     assert ref_final.min() >= 0.3, "the oracle runs must actually learn"
     finals, head, gap = [], None, None
     ydl.set_compute_dtype(mode)
     try:
         base = [_blobby128(100 + i, BS_, S_) for i in range(NB_)]
-        xv, tv = (t.cuda() for t in _blobby128(2, BS_, S_))
+        held_out = [tuple(t.cuda() for t in _blobby128(2 + i, BS_, S_)) for i in range(NVAL_)]
         for mi, eps in enumerate(fx["ens_eps"].tolist()):
             m = ydl.YOLOv5Seg(_cfg())
             m.img_size = [S_, S_]
@@ -172,10 +178,10 @@ def test_training_run_reaches_the_oracle_miou(mode):
                 opt.step()
                 losses.append(items[0])
             m.eval()
-            with torch.no_grad():
-                pv = m(xv)
             cm = ydl.ConfusionMatrix(12, ignore_index=11)
-            cm.process_batch(pv, tv)
+            with torch.no_grad():
+                for xv, tv in held_out:
+                    cm.process_batch(m(xv), tv)
             finals.append(cm.compute_iou()[0])
             if mi == 0:
                 losses = np.array(losses)

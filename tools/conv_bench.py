@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--acc", type=int, default=0, help="dgrad accumulate flag")
     ap.add_argument("--ring", type=int, default=1, help="0: igemm_kernel instead of the LDS-DMA ring kernel (igemm2)")
     ap.add_argument("--wg3", type=int, default=1, help="0: register-staged wgrad2 instead of the LDS-DMA wgrad3")
+    ap.add_argument("--persist", type=int, default=1, help="0: one tile per CTA instead of the persistent ring kernel (igemm2p)")
     ap.add_argument("--det", action="store_true", help="wgrad: deterministic slab + fixed-order reduce instead of f32 atomics")
     ap.add_argument("--check", action="store_true", help="compare fwd/dgrad of the ring kernel with igemm_kernel (max abs diff)")
     a = ap.parse_args()
@@ -41,6 +42,7 @@ def main():
     L.debug_set(1, a.pw)
     L.debug_set(3, a.ring)
     L.debug_set(4, a.wg3)
+    L.debug_set(6, a.persist)
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")

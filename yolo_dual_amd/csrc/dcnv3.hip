@@ -104,10 +104,12 @@ __global__ __launch_bounds__(256) void dcnv3_kernel(const DcnArgs a) {
                         } else if (act) {
                             float tg = go * mk;
                             float* gib = a.gin + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
-                            if (b1) atomicAdd(gib + o1, w1 * tg);
-                            if (b2) atomicAdd(gib + o2, w2 * tg);
-                            if (b3) atomicAdd(gib + o3, w3 * tg);
-                            if (b4) atomicAdd(gib + o4, w4 * tg);
+                            // a corner with bilinear weight 0 adds nothing: skip its atomic.  (Integer-aligned sampling positions — the
+                            // module starts with zero offsets, modules/dcnv3.py:101-107 — then touch one address per point, not four.)
+                            if (b1 && w1 != 0.f) atomicAdd(gib + o1, w1 * tg);
+                            if (b2 && w2 != 0.f) atomicAdd(gib + o2, w2 * tg);
+                            if (b3 && w3 != 0.f) atomicAdd(gib + o3, w3 * tg);
+                            if (b4 && w4 != 0.f) atomicAdd(gib + o4, w4 * tg);
                             float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
                             float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
                             gmask = go * val;

@@ -877,6 +877,235 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// igemm2p: the two-stage ring kernel as a PERSISTENT CTA that walks several output tiles, with the ring running across tile
+// boundaries.  In igemm2_kernel a tile costs t0 + n_k t1 with t0 (tap tables, row decode, the first DMA round trip, the epilogue's
+// LDS transpose, stores and statistics) as large as six K-steps; the step issued beyond a tile's last K-step was an all-zero dummy.
+// Here that slot carries the NEXT tile's first K-step: it is in flight while the current tile's last MFMAs and its whole epilogue
+// run, the epilogue uses the ring stage the last K-step just vacated as its scratch (a 128x128 bf16 tile is exactly one stage),
+// and the next tile's row descriptors are computed at the start of the current tile, under its first DMA wait.
+// Per K-step nothing changes: lgkmcnt(0), vmcnt(0) + s_barrier, issue the step after next, fragments, MFMAs (two stages:
+// the counted wait is vmcnt(0) anyway, so the epilogue's stores and atomics need no counting).  The stage of a tile's step 0 is
+// whatever parity the previous tile ended on (runtime parity, n_k may be odd).
+// Tile order: linear index = blockIdx.x + j * gridDim.x, mapped through xcd_remap over ALL tiles: with a grid that is a multiple
+// of 8 a CTA keeps drawing from its own XCD's contiguous tile range.
+// ------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NW, int WP>
+__global__ __launch_bounds__(NW * 64, NW / 2) void igemm2p_kernel(const IgemmArgs p) {
+    using T = bf16_t;
+    constexpr int ES = 2;
+    constexpr int S = 2;
+    constexpr int RPP = NW * 8;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows one pass covers");
+    constexpr int AR = BM / RPP, BR = BN / RPP;
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    constexpr int STAGE = (BM + BN) * GROWB;
+    static_assert(STAGE >= BM * BN * 2 && STAGE >= WP * BN * 8 + 64, "a stage must hold the epilogue's transposed tile and its statistics scratch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sTapA = (int*)(smem + S * STAGE);
+    int* sTapB = sTapA + MAXTAPS;
+    int* sTapD = sTapB + MAXTAPS;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WN, wp = wave / WN;
+    const int ntiles = p.grid_m * p.grid_n;
+    // tap tables of every class (global tap index): written once
+    if (t < MAXTAPS) {
+        int total = p.ntaps;
+        if (p.ncls > 1) { total = 0; for (int c = 0; c < p.ncls; ++c) total += p.cls_ntaps[c]; }
+        int da = 0, db = 0, dd = 0;
+        if (t < total) {
+            da = ((int)p.dh[t] * p.Wi + (int)p.dw[t]) * p.lda * ES;
+            db = (int)p.wt[t] * p.Kc * ES;
+            dd = ((int)p.dh[t] & 0xffff) | ((int)p.dw[t] << 16);
+        }
+        sTapA[t] = da; sTapB[t] = db; sTapD[t] = dd;
+    }
+    __syncthreads();
+
+    const int r = t >> 3;
+    const int qs = t & 7;
+    const unsigned q16 = (unsigned)((qs ^ ((r >> 1) & 7)) << 4);
+    const int spt = p.Kc >> 6;
+    u32x4 rsA, rsB;
+    {
+        const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+        rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
+        rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xffffu, p.bytesB, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_lds = lds0 + (unsigned)wave * (8 * GROWB);
+
+    struct TileInfo { int mtile, m0, n0, ntaps, tap0, Hg, Wg, M, h0, w0; };
+    auto tile_info = [&](int lin) {
+        TileInfo ti;
+        const int tile = xcd_remap(lin, ntiles);
+        int mtile, ntile;
+        if (p.m_fastest) { ntile = tile / p.grid_m; mtile = tile - ntile * p.grid_m; }
+        else { mtile = tile / p.grid_n; ntile = tile - mtile * p.grid_n; }
+        ti.ntaps = p.ntaps; ti.tap0 = 0; ti.Hg = p.Hg; ti.Wg = p.Wg; ti.M = p.M; ti.h0 = p.out_h0; ti.w0 = p.out_w0;
+        if (p.ncls > 1) {
+            int c = 0;
+            while (c + 1 < p.ncls && mtile >= p.cls_tile0[c + 1]) ++c;
+            mtile -= p.cls_tile0[c];
+            ti.ntaps = p.cls_ntaps[c]; ti.tap0 = p.cls_tap0[c]; ti.Hg = p.cls_Hg[c]; ti.Wg = p.cls_Wg[c]; ti.M = p.cls_M[c];
+            ti.h0 = p.cls_h0[c]; ti.w0 = p.cls_w0[c];
+        }
+        // wave-uniform by construction; say so (the class tables are indexed dynamically, which lands them in VGPRs)
+        mtile = __builtin_amdgcn_readfirstlane(mtile); ntile = __builtin_amdgcn_readfirstlane(ntile);
+        ti.ntaps = __builtin_amdgcn_readfirstlane(ti.ntaps); ti.tap0 = __builtin_amdgcn_readfirstlane(ti.tap0);
+        ti.Hg = __builtin_amdgcn_readfirstlane(ti.Hg); ti.Wg = __builtin_amdgcn_readfirstlane(ti.Wg);
+        ti.M = __builtin_amdgcn_readfirstlane(ti.M); ti.h0 = __builtin_amdgcn_readfirstlane(ti.h0);
+        ti.w0 = __builtin_amdgcn_readfirstlane(ti.w0);
+        ti.mtile = mtile; ti.m0 = mtile * BM; ti.n0 = ntile * BN;
+        return ti;
+    };
+    // per-thread DMA descriptors of a tile: byte offset of the (0,0) tap of each of its A rows + tap-validity bits, B row offsets
+    auto describe = [&](const TileInfo& ti, unsigned (&rowoff)[AR], unsigned (&vmask)[AR], unsigned (&browoff)[BR]) {
+        int ih0[AR], iw0[AR];
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int m = ti.m0 + r + RPP * i;
+            rowoff[i] = 0; vmask[i] = 0; ih0[i] = -100000; iw0[i] = 0;
+            if (m < ti.M) {
+                const int gw = m % ti.Wg;
+                const int tmp = m / ti.Wg;
+                const int gh = tmp % ti.Hg;
+                const int n = tmp / ti.Hg;
+                ih0[i] = gh * p.in_mul;
+                iw0[i] = gw * p.in_mul;
+                rowoff[i] = (unsigned)(((n * p.Hi + ih0[i]) * p.Wi + iw0[i]) * p.lda) * (unsigned)ES + q16;
+            }
+        }
+        for (int tp = 0; tp < ti.ntaps; ++tp) {
+            const int dd = sTapD[ti.tap0 + tp];
+            const int dh = (int)(short)(dd & 0xffff), dw = dd >> 16;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = (unsigned)(ih0[i] + dh) < (unsigned)p.Hi && (unsigned)(iw0[i] + dw) < (unsigned)p.Wi;
+                vmask[i] |= ok ? (1u << tp) : 0u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int co = ti.n0 + r + RPP * i;
+            browoff[i] = co < p.Cout ? (unsigned)co * p.ldb_bytes + q16 : 0xF0000000u;
+        }
+    };
+
+    // ---- issue cursor: the K-step to DMA next; runs ahead of the MFMAs by one step and crosses into the next tile
+    unsigned c_rowoff[AR], c_vmask[AR], c_browoff[BR];      // descriptors of the tile the cursor is in
+    unsigned n_rowoff[AR], n_vmask[AR], n_browoff[BR];      // ... of the tile after it (prepared at the start of a tile)
+    int ic_tap = 0, ic_cb = 0, ic_ntaps = 0, ic_tap0 = 0;
+    int nx_ntaps = 0, nx_tap0 = 0;
+    bool ic_valid = false, nx_valid = false;
+    auto issue = [&](int stg) {
+        const int da = sTapA[ic_tap0 + ic_tap], db = sTapB[ic_tap0 + ic_tap];
+        const bool live = ic_valid;                               // beyond the CTA's last tile: every lane out of range (zeros)
+        const unsigned kb = (unsigned)ic_cb << 7;
+        const unsigned tbit = live ? 1u << ic_tap : 0u;
+        const unsigned kbB = live ? kb : 0xF0000000u;
+        const unsigned base = __builtin_amdgcn_readfirstlane(wave_lds + (unsigned)stg * STAGE);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const unsigned off = (c_vmask[i] & tbit) ? (c_rowoff[i] + (unsigned)da + kb) : 0xFFFFFFFFu;
+            lds_dma16(rsA, base + i * RPP * GROWB, off);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) lds_dma16(rsB, base + BM * GROWB + i * RPP * GROWB, c_browoff[i] + (unsigned)db + kbB);
+        if (live && ++ic_tap == ic_ntaps) {
+            ic_tap = 0;
+            if (++ic_cb == spt) {                                 // the cursor leaves its tile
+                ic_cb = 0;
+                ic_valid = nx_valid;
+                ic_ntaps = nx_ntaps; ic_tap0 = nx_tap0;
+#pragma unroll
+                for (int i = 0; i < AR; ++i) { c_rowoff[i] = n_rowoff[i]; c_vmask[i] = n_vmask[i]; }
+#pragma unroll
+                for (int i = 0; i < BR; ++i) c_browoff[i] = n_browoff[i];
+                nx_valid = false;
+            }
+        }
+    };
+
+    const int lrow = lane & 15;
+    const int sw_rd = (lrow >> 1) & 7;
+    const int lk0 = (((lane >> 4)) ^ sw_rd) << 4;
+    const int lk1 = (((lane >> 4) + 4) ^ sw_rd) << 4;
+    const unsigned char* const fa = smem + BM * GROWB + (wc * BNW + lrow) * GROWB;
+    const unsigned char* const fb = smem + (wp * (BM / WP) + lrow) * GROWB;
+    uint4 af0[CT], bf0[PT], af1[CT], bf1[PT];
+    auto rdfrag = [&](int stg, int half, uint4 (&af)[CT], uint4 (&bfr)[PT]) {
+        const unsigned char* a_base = fa + stg * STAGE + (half ? lk1 : lk0);
+        const unsigned char* b_base = fb + stg * STAGE + (half ? lk1 : lk0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * GROWB);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * GROWB);
+    };
+
+    // (the launcher guarantees n_k >= 2 for every tile: the cursor then never runs further ahead than the tile whose descriptors
+    //  were prepared at the start of the tile the MFMAs are in)
+    int lin = blockIdx.x;
+    if (lin >= ntiles) return;
+    TileInfo cur = tile_info(lin);
+    describe(cur, c_rowoff, c_vmask, c_browoff);
+    ic_valid = true; ic_ntaps = cur.ntaps; ic_tap0 = cur.tap0;
+    int par = 0;
+    issue(par);                            // step 0 of the first tile
+    for (; lin < ntiles; lin += gridDim.x) {
+        const int nk = cur.ntaps * spt;
+        // descriptors of the tile after this one, before the cursor can reach it (it is at step 1 of this tile now)
+        const int lin_n = lin + gridDim.x;
+        TileInfo nxt = cur;
+        nx_valid = lin_n < ntiles;
+        if (nx_valid) {
+            nxt = tile_info(lin_n);
+            describe(nxt, n_rowoff, n_vmask, n_browoff);
+            nx_ntaps = nxt.ntaps; nx_tap0 = nxt.tap0;
+        }
+        f32x4 acc[CT][PT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma = [&](const uint4 (&af)[CT], const uint4 (&bfr)[PT]) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+        };
+        wait_vm_barrier<0>();              // step 0 landed everywhere; everyone is past the previous tile's epilogue
+        issue(par ^ 1);                    // step 1
+        rdfrag(par, 0, af0, bf0);
+        for (int kk = 0; kk < nk; ++kk) {
+            const int stg = (par + kk) & 1;
+            rdfrag(stg, 1, af1, bf1);
+            mma(af0, bf0);
+            if (kk + 1 < nk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave holds all of step kk in registers
+                wait_vm_barrier<0>();                                   // step kk+1 landed everywhere
+                issue(stg);                                             // step kk+2 (possibly the next tile's step 0) -> the stage step kk occupied
+                rdfrag(stg ^ 1, 0, af0, bf0);
+            }
+            mma(af1, bf1);
+        }
+        const int sl = (par + nk - 1) & 1;     // the stage of the last K-step: free now, the epilogue's scratch
+        par = sl ^ 1;                          // the next tile's step 0 is landing in the other one
+        // every wave has its last fragments in registers before the scratch stage is overwritten (no vmcnt wait: the next tile's DMAs
+        // stay in flight through the epilogue)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        igemm2_epilogue<BM, BN, NW, WP>(p, acc, smem + sl * STAGE, cur.m0, cur.n0, cur.mtile, cur.M, cur.Wg, cur.Hg, cur.h0, cur.w0);
+        cur = nxt;
+    }
+    wait_vm_barrier<0>();              // trailing (all-zero) DMAs land before the CTA's LDS goes away
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Point-wise (1x1, stride 1) convolutions with a short K (row = 128..512 bytes of K) on large pixel counts.
 // These layers are HBM-bound (2 bytes in + 2 bytes out per MAC row) and the tiled kernel above runs them at ~45 % of
 // the HBM rate: with 2..4 K-steps a CTA is three dependent memory round trips (load, load, store) and two CTAs per CU
@@ -1002,8 +1231,19 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #pragma unroll
                     for (int ps = 0; ps < 16 / RPP; ++ps) {
                         const int row = ps * RPP + lane / NCH, ch = lane % NCH;
-                        const uint4 v4 = *(const uint4*)(tb + row * (NCH * 16) + ((ch ^ (row & swm)) << 4));
-                        if (tile_m + row < m_end) *(uint4*)((unsigned char*)(Yg + (size_t)(tile_m + row) * p.ldc + co0) + (ch << 4)) = v4;
+                        uint4 v4 = *(const uint4*)(tb + row * (NCH * 16) + ((ch ^ (row & swm)) << 4));
+                        if (tile_m + row < m_end) {
+                            uint4* gp = (uint4*)((unsigned char*)(Yg + (size_t)(tile_m + row) * p.ldc + co0) + (ch << 4));
+                            if (p.accumulate) {          // gradient fan-in: whole 16-byte read-modify-write rows (launcher: bf16, no statistics)
+                                float a8[16 / ES], o8[16 / ES];
+                                unpack16<T>(v4, a8);
+                                unpack16<T>(*gp, o8);
+#pragma unroll
+                                for (int e = 0; e < 16 / ES; ++e) a8[e] += o8[e];
+                                v4 = pack16<T>(a8);
+                            }
+                            *gp = v4;
+                        }
                     }
                     if (want_stats && m < m_end) {
 #pragma unroll
@@ -1317,7 +1557,13 @@ static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int 
     PwArgs a2 = a;
     static const int no_t = getenv("YDL_PW_NOTSTORE") ? atoi(getenv("YDL_PW_NOTSTORE")) : 0;
     // (bf16 only: the f32 instantiations lose an occupancy step or spill with the extra staging code; parity mode keeps direct stores)
-    a2.tstore = (sizeof(T) == 2 && !a.accumulate && !no_t && pl.smem + pl.tstage <= 158 * 1024) ? 1 : 0;
+    // (an accumulating launch takes the transposed path when it carries no statistics: the input-gradient fan-in.  Its own
+    //  contribution is rounded to bf16 in the staging tile before the add — one rounding more than the direct path.)
+    static const int acc_ts = getenv("YDL_PW_ACC_TS") ? atoi(getenv("YDL_PW_ACC_TS")) : 1;
+    // measured per layer (tools/conv_bench.py dgrad --acc 1): faster everywhere (-8 ... -27 %) but on 256-byte K rows with 128-channel
+    // wave tiles, where the direct read-modify-write wins (128->128 @160^2: 90 vs 111 us)
+    const bool acc_ok = a.stats == nullptr && acc_ts && !(RB == 256 && CT == 8);
+    a2.tstore = (sizeof(T) == 2 && (!a.accumulate || acc_ok) && !no_t && pl.smem + pl.tstage <= 158 * 1024) ? 1 : 0;
     {
         // the store path is part of the recorded name: "ts" = per-wave LDS-transposed 16-byte stores, "direct" = register-layout stores
         static const std::string base = std::string("pw_kernel<") + (sizeof(T) == 4 ? "f32" : "bf16") + "," + std::to_string(RB) + "," +
@@ -1376,6 +1622,7 @@ static int launch_igemm(IgemmArgs a, hipStream_t st, int fam) {
 
 struct TileCfg { int BM, BN; int ring; };     // ring != 0: igemm2_kernel (bf16 LDS-DMA ring) instantiation id
 static int g_ring_enabled = 1;
+static int g_ring_persist = 1;
 
 template <int BM, int BN, int NW, int WP, int S>
 static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
@@ -1405,12 +1652,36 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
         a.dbg = dbg;
     }
     const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
-    YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S>), smem);
-    {
-        static const std::string nm = std::string("igemm2_kernel<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
-                                      std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + ">";
-        ydl_note_kernel(fam, nm.c_str());
+    static const std::string nm = std::string("igemm2_kernel<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
+                                  std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + ">";
+    if constexpr (S == 2) {
+        // persistent form (igemm2p_kernel): worth it when a CTA gets more than one tile; needs n_k >= 2 in every class
+        static const int persist = getenv("YDL_RING_PERSIST") ? atoi(getenv("YDL_RING_PERSIST")) : 1;
+        const int spt = a.Kc >> 6;
+        int min_taps = a.ntaps;
+        if (a.ncls > 1) { min_taps = 1 << 30; for (int c = 0; c < a.ncls; ++c) min_taps = min(min_taps, a.cls_ntaps[c]); }
+        static int per_cu = -1;                  // resident CTAs per CU of this instantiation (registers and LDS)
+        YDL_SET_MAX_LDS((igemm2p_kernel<BM, BN, NW, WP>), smem);
+        if (per_cu < 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, igemm2p_kernel<BM, BN, NW, WP>, NW * 64, smem) != hipSuccess) nb = 0;
+            per_cu = nb;
+        }
+        int G = ydl_device_cus() * per_cu;
+        G -= G % 8;
+        const int ntiles = mtiles * a.grid_n;
+        // measured (tools/conv_bench.py --persist 0/1, config-2 layers): +5..10 % with 128-wide tiles once a CTA walks >= 2.5 tiles,
+        // neutral to -12 % below that (a second resident CTA overlaps better than a short walk) and with 64-wide tiles
+        if (persist && g_ring_persist && BN == 128 && min_taps * spt >= 2 && G >= 8 && 2 * ntiles >= 5 * G) {
+            static const std::string nmp = nm + ":persistent";
+            ydl_note_kernel(fam, nmp.c_str());
+            igemm2p_kernel<BM, BN, NW, WP><<<G, NW * 64, smem, st>>>(a);
+            YDL_LAUNCH_CHECK();
+            return 0;
+        }
     }
+    YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S>), smem);
+    ydl_note_kernel(fam, nm.c_str());
     igemm2_kernel<BM, BN, NW, WP, S><<<grid, NW * 64, smem, st>>>(a);
     YDL_LAUNCH_CHECK();
     return 0;
@@ -2371,6 +2642,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 2 = strided dgrad: 1 (default) all output-parity classes in one launch, 0 one launch per class
 //              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
 //              key 3 = bf16 LDS-DMA ring kernel (igemm2) for the MFMA-bound layers: 1 (default) on, 0 off (igemm_kernel everywhere)
+//              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
 //              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
 // Process-wide and test-only: they change launch geometry, so callers that cache ydl_conv_fwd_grid_m/... must drop the cache
@@ -2382,6 +2654,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 3) g_ring_enabled = val;
     if (key == 4) g_wgrad_dma = val;
     if (key == 5) g_stem_enabled = val;
+    if (key == 6) g_ring_persist = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
