@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from yolo_dual_amd import _lib as L
+if os.environ.get("YDL_LIB_PATH"):          # timing experiments with a variant build of the library
+    L.LIB_PATH = os.environ["YDL_LIB_PATH"]
 
 SHAPES = [(1638400, 64, 12800), (409600, 128, 3200), (409600, 64, 3200), (102400, 256, 800), (25600, 512, 400), (6400, 1024, 100), (6400, 512, 100),
           (409600, 128, 493)]   # (npix, C, conv partial rows)

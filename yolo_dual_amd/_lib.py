@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YDL_LIB", os.path.join(_HERE, "lib", "libydl_hip.so"))   # YDL_LIB: dev override for A/B builds
 
 YDL_F32, YDL_BF16, YDL_F16 = 0, 1, 2
-BN_REPLICAS = 8          # YDL_BN_REPLICAS of ydl.h
+BN_REPLICAS = 8             # YDL_BN_REPLICAS of ydl.h
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 RES_GRAD_ACCUMULATE = 16
@@ -190,6 +190,7 @@ def profile_end():
         d = {"name": name, "ms": e0.elapsed_time(e1), "flops": flops, "bytes": nbytes}
         if g is not None:
             d["geom"] = [getattr(g, f) for f, _ in ConvGeom._fields_]
+            d["kernel"], d["accumulate"] = getattr(g, "_kernel", ""), getattr(g, "_acc", 0)
         out.append(d)
     return out
 
@@ -230,6 +231,8 @@ def call(name: str, *args):
         src = args[0]._obj
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
         g._es = 4 if args[1] == YDL_F32 else 2
+        g._kernel = last_kernel(1 if name == "ydl_conv_dgrad" else 2 if "wgrad" in name else 0)
+        g._acc = int(args[5]) if name == "ydl_conv_dgrad" else int(args[6]) if name.startswith("ydl_conv_fwd") else 0
     elif name == "ydl_bn_act_fwd":          # algorithmic bytes: y (+ residual) read once, out written once
         es = 4 if args[0] == YDL_F32 else 2
         g = float(args[11]) * args[12] * es * (2 + (1 if args[7] else 0))

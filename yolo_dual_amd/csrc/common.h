@@ -60,7 +60,11 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
 // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the IEEE division / range-reduced exp sequences (about 25 VALU instructions per
 // element, which made the streaming BN kernels VALU-bound).  exp2 overflow gives rcp(inf) = 0, underflow gives rcp(1) = 1.
 __device__ __forceinline__ float sigmoid_f(float z) {
+#ifdef YDL_FAKE_SIGMOID      // timing experiment only (what the two transcendentals cost the streaming kernels): wrong results
+    return 0.5f + 0.125f * z;
+#else
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+#endif
 }
 __device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
 

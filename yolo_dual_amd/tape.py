@@ -247,6 +247,19 @@ class Tape:
                 v.g, _ = _alloc(v.N, v.C, v.H, v.W, v.t.dtype, self.device)
         return v.g
 
+    def _alias_grad(self, v: Var, o: Var, dout: torch.Tensor) -> bool:
+        """A residual joined after the activation has d/dv = dout: when v's gradient has no buffer and no writer yet, and both are
+        whole buffers of the same layout, v adopts dout's storage (later writers accumulate into it; dout's consumer, the BN
+        backward that calls this, reads it before anything else is enqueued).  Saves one write pass over the tensor."""
+        v, o = v.root(), o.root()
+        if (v.g is not None or v.is_set() or v.parent is not None or o.parent is not None or v.children or o.children
+                or v.lazy or o.lazy or v.ld != o.ld or (v.N, v.C, v.H, v.W) != (o.N, o.C, o.H, o.W) or v.t.dtype != o.t.dtype
+                or dout.shape != o.t.shape):
+            return False
+        v.g = dout
+        v.gset = True
+        return True
+
     def grad_target(self, v: Var) -> (torch.Tensor, int):
         """(buffer, accumulate) for a kernel about to write d/dv; marks v as set."""
         v = v.root()
@@ -556,7 +569,9 @@ class Tape:
                 # gradient of the residual branch, written (or added) by the same kernel pass: dz for a residual joined before the
                 # activation, dout itself for one joined after it
                 dres_t, dres_ld, rmode = None, 0, res_mode
-                if res is not None and res.need and res_mode in (L.RES_BEFORE_ACT, L.RES_AFTER_ACT):
+                if res is not None and res.need and res_mode == L.RES_AFTER_ACT and self._alias_grad(res, o, dout):
+                    pass          # d/dres IS dout and nothing else has written it yet: res takes dout's buffer, no copy pass
+                elif res is not None and res.need and res_mode in (L.RES_BEFORE_ACT, L.RES_AFTER_ACT):
                     gbuf, racc = self.grad_target(res)
                     dres_t, dres_ld = gbuf, res.ld
                     if racc:
