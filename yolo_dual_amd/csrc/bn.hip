@@ -180,6 +180,9 @@ extern "C" int ydl_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
 // in registers) and walks pixels with a 32-bit stride; a CTA covers R = 256/cpb pixels per iteration, where
 // cpb = min(chunks per pixel, 256).  No 64-bit divisions, no per-element coefficient loads.
 // ------------------------------------------------------------------------------------------------------
+#ifndef BN_APPLY_REVERSE
+#define BN_APPLY_REVERSE 1
+#endif
 struct Lay { int cpb, R, cq, pl; bool live; int c; };
 template <int V>
 __device__ __forceinline__ Lay make_lay(int Cp) {
@@ -448,7 +451,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         kb[e] = sums[L.c + e] * invM; kg[e] = sums[Cp + L.c + e] * invM;
     }
     const long long stride = (long long)gridDim.x * L.R;
-    for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
+    // the second pass walks the tensor BACKWARDS: what the reduce pass read last is the likeliest to still sit in L2 / the
+    // Infinity Cache (BN_APPLY_REVERSE=0: same order as the reduce pass, for A/B timing)
+    const long long pfirst = (long long)blockIdx.x * L.R + L.pl;
+    const long long plast = pfirst < npix ? pfirst + (npix - 1 - pfirst) / stride * stride : pfirst - stride;
+    for (long long pix = BN_APPLY_REVERSE ? plast : pfirst; BN_APPLY_REVERSE ? pix >= pfirst : pix < npix;
+         pix += BN_APPLY_REVERSE ? -stride : stride) {
         float dz[V], xh[V], o[V], dv[V];
         dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh, dv);
 #pragma unroll
@@ -781,7 +789,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
         kb[e] = s_kb[L.cq * V + e]; kg[e] = s_kg[L.cq * V + e];
     }
     const long long stride = (long long)gridDim.x * L.R;
-    for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
+    // the second pass walks the tensor BACKWARDS: what the reduce pass read last is the likeliest to still sit in L2 / the
+    // Infinity Cache (BN_APPLY_REVERSE=0: same order as the reduce pass, for A/B timing)
+    const long long pfirst = (long long)blockIdx.x * L.R + L.pl;
+    const long long plast = pfirst < npix ? pfirst + (npix - 1 - pfirst) / stride * stride : pfirst - stride;
+    for (long long pix = BN_APPLY_REVERSE ? plast : pfirst; BN_APPLY_REVERSE ? pix >= pfirst : pix < npix;
+         pix += BN_APPLY_REVERSE ? -stride : stride) {
         float dz[V], xh[V], o[V], dv[V];
         dz_xhat<T, ACT>(y, dout, out, pix, ldy, lddo, ldo, L.c, sc, sf, mu, is, dz, xh, dv);
 #pragma unroll
