@@ -161,6 +161,16 @@ int ydl_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int ldy, uint8_t
                     int N, int Hi, int Wi, int Ho, int Wo, int C, int k, int s, int p, void* stream);
 int ydl_maxpool_bwd(int dtype, const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, int accumulate,
                     int N, int Hi, int Wi, int Ho, int Wo, int C, int k, int s, int p, void* stream);
+/* SPPF's chain of three k x k / stride 1 / pad k/2 max-pools (y1 = mp(x), y2 = mp(y1), y3 = mp(y2); seg_diceloss_yolov5.py:468-481,
+ * models/common.py:223-238) in one launch per direction, the H x W plane held in LDS: same values, index planes and gradients as
+ * three ydl_maxpool_fwd / ydl_maxpool_bwd calls, bit for bit.  ydl_sppf_pool_supported: 1 when the plane fits (else use those).
+ * Backward: dyK = gradient already present in the slice of yK (the concat consumer's input gradient), dx (+)= the chain's result. */
+int ydl_sppf_pool_supported(int dtype, int H, int W, int C, int k);
+int ydl_sppf_pool_fwd(int dtype, const void* x, int ldx, void* y1, void* y2, void* y3, int ldy,
+                      uint8_t* idx1, uint8_t* idx2, uint8_t* idx3, int N, int H, int W, int C, int k, void* stream);
+int ydl_sppf_pool_bwd(int dtype, const void* dy1, const void* dy2, const void* dy3, int lddy, const uint8_t* idx1,
+                      const uint8_t* idx2, const uint8_t* idx3, void* dx, int lddx, int accumulate,
+                      int N, int H, int W, int C, int k, void* stream);
 /* resize: mode 0 nearest (src=min(floor(dst*scale),in-1)), 1 bilinear align_corners=False, 2 bilinear
  * align_corners=True.  scale_h/w <= 0 means "derive from sizes" (in/out, or (in-1)/(out-1)). */
 int ydl_resize_fwd(int dtype, int mode, const void* x, int ldx, void* y, int ldy,
@@ -244,6 +254,12 @@ int ydl_sgd_ema_step(float* params, const float* grads, float* momentum, float* 
 int ydl_sgd_ema_step_dev(float* params, const float* grads, float* momentum, float* ema,
                          int64_t n_decay, int64_t n_params, int64_t n_total, const float* hyper_dev,
                          int lr_index, int use_weight_decay, int first_step, int use_ema, void* stream);
+
+/* every run of one step in one launch: runs_dev = device int64[nruns][6] rows {offset (elements into all four arenas), n_decay,
+ * n_params, n_total, lr_index, flags: bit 0 weight decay, bit 1 first step}, each row with the meaning of the arguments of
+ * ydl_sgd_ema_step_dev applied at `offset`; max_run = the largest n_total (grid sizing). */
+int ydl_sgd_ema_step_multi(float* params, const float* grads, float* momentum, float* ema, const int64_t* runs_dev,
+                           int nruns, int64_t max_run, const float* hyper_dev, int use_ema, void* stream);
 
 /* ---- evaluation: argmax + confusion matrix (val_diceloss.py:37-75) ---------------------------------- */
 int ydl_confusion_matrix(const float* pred, int64_t sn, int64_t sc, int64_t sh, int64_t sw,

@@ -345,3 +345,46 @@ def test_wgrad_lds_dma_feed_equals_register_staged_kernel(shape):
     finally:
         L.debug_set(4, 1)
     assert torch.equal(res[0], res[1]), rel_err(res[0], res[1])
+
+
+@pytest.mark.parametrize("dtype,N,C,H,W,k", [("bf16", 3, 72, 20, 20, 5), ("f32", 2, 20, 13, 17, 5), ("bf16", 2, 16, 9, 31, 3),
+                                             ("bf16", 16, 512, 20, 20, 5)])
+def test_sppf_pool_chain_in_one_launch_equals_three_maxpools(dtype, N, C, H, W, k):
+    """ydl_sppf_pool_fwd / _bwd (SPPF's three chained 5x5 pools with the plane held in LDS, seg_diceloss_yolov5.py:468-481) against
+    three ydl_maxpool_fwd / ydl_maxpool_bwd launches on concat-slice layouts: outputs, arg-max planes and the gradient that
+    reaches x are equal bit for bit — bf16 activations are full of exact ties, so the first-maximum rule is exercised"""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    dt = L.YDL_BF16 if dtype == "bf16" else L.YDL_F32
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    V = 8 if dtype == "bf16" else 4
+    Cp = (C + V - 1) // V * V
+    ld = 4 * Cp
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.lib().ydl_sppf_pool_supported(dt, H, W, C, k) == 1
+    gen = torch.Generator("cuda").manual_seed(7)
+    res = []
+    for fused in (True, False):
+        cat = torch.zeros(N, H, W, ld, device="cuda", dtype=tdt)
+        cat[..., :C] = (torch.randn(N, H, W, C, device="cuda", generator=torch.Generator("cuda").manual_seed(7)) * 2).round().to(tdt) / 2
+        sl = [cat[..., i * Cp:] for i in range(4)]
+        idx = [torch.zeros(N * H * W * Cp, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        dcat = torch.randn(N, H, W, ld, device="cuda", generator=torch.Generator("cuda").manual_seed(9)).to(tdt)
+        dsl = [dcat[..., i * Cp:] for i in range(4)]
+        if fused:
+            L.call("ydl_sppf_pool_fwd", dt, P(sl[0]), ld, P(sl[1]), P(sl[2]), P(sl[3]), ld, P(idx[0]), P(idx[1]), P(idx[2]), N, H, W, C, k, st)
+            L.call("ydl_sppf_pool_bwd", dt, P(dsl[1]), P(dsl[2]), P(dsl[3]), ld, P(idx[0]), P(idx[1]), P(idx[2]), P(dsl[0]), ld, 1,
+                   N, H, W, C, k, st)
+        else:
+            for i in range(3):
+                L.call("ydl_maxpool_fwd", dt, P(sl[i]), ld, P(sl[i + 1]), ld, P(idx[i]), N, H, W, H, W, C, k, 1, k // 2, st)
+            for i in (2, 1, 0):
+                L.call("ydl_maxpool_bwd", dt, P(dsl[i + 1]), ld, P(idx[i]), P(dsl[i]), ld, 1, N, H, W, H, W, C, k, 1, k // 2, st)
+        torch.cuda.synchronize()
+        res.append((cat.float().cpu(), [i.cpu() for i in idx], dcat[..., :Cp].float().cpu()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert float(res[0][0][..., Cp:2 * Cp].abs().max()) > 0          # the pools did write
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][2], res[1][2])

@@ -56,6 +56,9 @@ SIGNATURES = {
     "ydl_bn_bwd_ws_bytes": (_i64, [_i64, _i]),
     "ydl_bn_act_bwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i,
                             _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
+    "ydl_sppf_pool_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ydl_sppf_pool_fwd": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ydl_sppf_pool_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ydl_maxpool_fwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ydl_maxpool_bwd": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ydl_resize_fwd": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
@@ -81,6 +84,7 @@ SIGNATURES = {
     "ydl_seg_loss_rep_bwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _f, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ydl_sgd_ema_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "ydl_sgd_ema_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp]),
+    "ydl_sgd_ema_step_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _i, _vp]),
     "ydl_confusion_matrix": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ydl_dcnv3_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp]),
     "ydl_dcnv3_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f,

@@ -41,6 +41,41 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
     }
 }
 
+// replicated output, rw == 4, unit W stride: one thread per STORED pixel computes the softmax once and writes its rh x 4 replicas as
+// 16-byte stores (a wave-instruction covers 1 KiB of one output row); the generic kernel recomputed the 12 exponentials for each
+// of the 16 replicas and was bound by them (97 us for the 315 MB export of BASELINE config 2, 58 us here)
+template <typename T, int MC>
+__global__ __launch_bounds__(256) void softmax_fwd_rep4_kernel(const T* __restrict__ x, int ldx, float* __restrict__ p,
+                                                               long long sn, long long sc, long long sh,
+                                                               int N, int H, int W, int C, int rh) {
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const long long t2 = i / W;
+        const int h = (int)(t2 % H);
+        const int n = (int)(t2 / H);
+        const T* xp = x + (size_t)i * ldx;
+        float v[MC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) { v[c] = ET<T>::ld(xp + c); mx = fmaxf(mx, v[c]); }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) { v[c] = expf(v[c] - mx); s += v[c]; }
+        const float inv = 1.f / s;
+        float* pp = p + n * sn + (long long)(h * rh) * sh + (long long)w * 4;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < C) {
+                const float q = v[c] * inv;
+                const float4 q4 = make_float4(q, q, q, q);
+                for (int a = 0; a < rh; ++a) *(float4*)(pp + c * sc + a * sh) = q4;
+            }
+    }
+}
+
 template <typename T, int MC>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
                                                           long long sn, long long sc, long long sh, long long sw,
@@ -83,6 +118,13 @@ extern "C" int ydl_softmax_fwd(int dtype, const void* x, int ldx, float* p, int6
                                int N, int H, int W, int C, int rep_h, int rep_w, void* stream) {
     YDL_CHECK(x && p && C >= 1 && C <= MAXC && ldx >= C && rep_h >= 1 && rep_w >= 1, "bad arguments (C <= 32)");
     hipStream_t st = (hipStream_t)stream;
+    if (rep_w == 4 && sw == 1 && C <= 16 && ((uintptr_t)p & 15) == 0 && sn % 4 == 0 && sc % 4 == 0 && sh % 4 == 0) {
+        const int g2 = sgrid((long long)N * H * W);
+        if (dtype == YDL_F32) softmax_fwd_rep4_kernel<float, 16><<<g2, 256, 0, st>>>((const float*)x, ldx, p, sn, sc, sh, N, H, W, C, rep_h);
+        else softmax_fwd_rep4_kernel<bf16_t, 16><<<g2, 256, 0, st>>>((const bf16_t*)x, ldx, p, sn, sc, sh, N, H, W, C, rep_h);
+        YDL_LAUNCH_CHECK();
+        return 0;
+    }
     int grid = sgrid((long long)N * H * W * rep_h * rep_w);
     if (dtype == YDL_F32) {
         if (C <= 16) softmax_fwd_kernel<float, 16><<<grid, 256, 0, st>>>((const float*)x, ldx, p, sn, sc, sh, sw, N, H, W, C, rep_h, rep_w);

@@ -47,18 +47,42 @@ extern "C" int ydl_weight_prep(int dtype, const float* master, void* w, void* wt
 // written in the same order and `wt` transposed, both coalesced (the former element-wise version read the master with a
 // k*k*Cin stride for `wt`: 549 MB fetched per step for 68 MB of weights in the PMC profile).
 template <typename T>
-__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const long long* __restrict__ desc) {
-    const long long* d = desc + (size_t)blockIdx.y * 8;
-    const float* master = (const float*)d[0];
-    T* w = (T*)d[1];
-    T* wt = (T*)d[2];
-    const int Cout = (int)d[3], kk = (int)d[4], Cin = (int)d[5];
-    const int Cin_p = (Cin + 7) / 8 * 8, Cout_p = (Cout + 7) / 8 * 8;
-    const int tco = (Cout_p + 31) / 32, tci = (Cin_p + 31) / 32;
-    const int ntiles = tco * tci * kk;
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const long long* __restrict__ desc, int nlayers) {
+    // tiles of ALL layers in one flat index space (one grid row per layer gave the 4.7 M-element layers 256 CTAs like the 8 K-element
+    // ones: the launch took as long as its largest layer, 58 us for 68 MB in / 68 MB out).  Every CTA derives the per-layer tile
+    // prefix itself: layer = thread, inclusive scan through LDS.
+    __shared__ int s_end[256];
     __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int tid = threadIdx.x;
+    {
+        int nt = 0;
+        if (tid < nlayers) {
+            const long long* d = desc + (size_t)tid * 8;
+            const int Cout = (int)d[3], kk = (int)d[4], Cin = (int)d[5];
+            nt = ((Cout + 7) / 8 * 8 + 31) / 32 * (((Cin + 7) / 8 * 8 + 31) / 32) * kk;
+        }
+        s_end[tid] = nt;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = tid >= o ? s_end[tid - o] : 0;
+            __syncthreads();
+            s_end[tid] += v;
+            __syncthreads();
+        }
+    }
+    const int total = s_end[nlayers - 1];
+    const int tx = tid & 31, ty = tid >> 5;
+    int l = 0;
+    for (int gt = blockIdx.x; gt < total; gt += gridDim.x) {
+        while (gt >= s_end[l]) ++l;                       // gt only grows
+        const long long* d = desc + (size_t)l * 8;
+        const float* master = (const float*)d[0];
+        T* w = (T*)d[1];
+        T* wt = (T*)d[2];
+        const int Cout = (int)d[3], kk = (int)d[4], Cin = (int)d[5];
+        const int Cin_p = (Cin + 7) / 8 * 8, Cout_p = (Cout + 7) / 8 * 8;
+        const int tci = (Cin_p + 31) / 32;
+        const int tl = gt - (l ? s_end[l - 1] : 0);
         const int cit = tl % tci;
         const int r2 = tl / tci;
         const int t = r2 % kk;
@@ -83,10 +107,13 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const long lon
 
 extern "C" int ydl_weight_prep_batched(int dtype, const int64_t* desc_dev, int nlayers, void* stream) {
     YDL_CHECK(desc_dev && nlayers > 0, "bad arguments");
-    dim3 grid(256, nlayers);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == YDL_F32) weight_prep_batched_kernel<float><<<grid, 256, 0, st>>>((const long long*)desc_dev);
-    else weight_prep_batched_kernel<bf16_t><<<grid, 256, 0, st>>>((const long long*)desc_dev);
+    for (int l0 = 0; l0 < nlayers; l0 += 256) {            // 256 layers per launch (one scan lane each)
+        const int nl = nlayers - l0 < 256 ? nlayers - l0 : 256;
+        const long long* d = (const long long*)desc_dev + (size_t)l0 * 8;
+        if (dtype == YDL_F32) weight_prep_batched_kernel<float><<<2048, 256, 0, st>>>(d, nl);
+        else weight_prep_batched_kernel<bf16_t><<<2048, 256, 0, st>>>(d, nl);
+    }
     YDL_LAUNCH_CHECK();
     return 0;
 }
@@ -241,6 +268,51 @@ __global__ __launch_bounds__(256) void sgd_ema_dev_kernel(float* __restrict__ pa
             ema[i] = e;
         }
     }
+}
+
+// All runs of one optimizer step in ONE launch: grid row y handles run y = {offset, n_decay, n_params, n_total, lr_index,
+// flags (bit 0 weight decay, bit 1 first step)} of the device table (the per-run launches of the dead / live / BN / bias / buffer
+// ranges cost ~7 us each, nine of them per step on BASELINE config 2).  Same arithmetic as sgd_ema_dev_kernel.
+__global__ __launch_bounds__(256) void sgd_ema_multi_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                                            float* __restrict__ mombuf, float* __restrict__ ema,
+                                                            const long long* __restrict__ runs, const float* __restrict__ hyper,
+                                                            int use_ema) {
+    const long long* r = runs + (size_t)blockIdx.y * 6;
+    const long long off = r[0], n_decay = r[1], n_params = r[2], n_total = r[3];
+    const int lr_idx = (int)r[4], flags = (int)r[5];
+    const int first = (flags >> 1) & 1;
+    const float lr = hyper[lr_idx], mom = hyper[3], wd = (flags & 1) ? hyper[4] : 0.f, gscale = hyper[5], d = hyper[6];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (long long)gridDim.x * blockDim.x) {
+        float p = params[off + i];
+        if (i < n_params) {
+            bool dec = i < n_decay;
+            float g = grads[off + i] * gscale;
+            if (dec && wd != 0.f) g = g + wd * p;
+            float b = first ? g : mom * mombuf[off + i] + g;
+            mombuf[off + i] = b;
+            float upd = g + mom * b;
+            p = p - lr * upd;
+            params[off + i] = p;
+        }
+        if (use_ema && ema != nullptr) {
+            float e = ema[off + i];
+            e = e * d;
+            e = e + (1.f - d) * p;
+            ema[off + i] = e;
+        }
+    }
+}
+
+extern "C" int ydl_sgd_ema_step_multi(float* params, const float* grads, float* momentum, float* ema, const int64_t* runs_dev,
+                                      int nruns, int64_t max_run, const float* hyper_dev, int use_ema, void* stream) {
+    YDL_CHECK(params && grads && momentum && runs_dev && hyper_dev && nruns > 0 && nruns <= 65535 && max_run >= 0, "bad arguments");
+    long long gx = (max_run + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    sgd_ema_multi_kernel<<<dim3((unsigned)gx, (unsigned)nruns), 256, 0, (hipStream_t)stream>>>(params, grads, momentum, ema,
+                                                                                             (const long long*)runs_dev, hyper_dev, use_ema);
+    YDL_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int ydl_sgd_ema_step_dev(float* params, const float* grads, float* momentum, float* ema,

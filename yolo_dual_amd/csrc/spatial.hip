@@ -126,6 +126,230 @@ extern "C" int ydl_maxpool_bwd(int dtype, const void* dy, int lddy, const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------------
+// SPPF's three chained k x k / stride 1 max-pools (seg_diceloss_yolov5.py:468-481: y1 = mp(x), y2 = mp(y1), y3 = mp(y2)) in ONE
+// launch per direction.  A CTA owns the whole H x W plane of one image for SP_CG 16-byte channel chunks and keeps it in LDS, so
+// the chain never goes back to memory between the pools (three launches of 22-25 us forward and 30-34 us backward on 6.5 MB
+// tensors: latency, not bytes).  Values, arg-max codes and the backward's summation order are those of maxpool_fwd_kernel /
+// maxpool_bwd_kernel (first maximum in scan order; every stage rounded to the storage type) — the results are bit-identical.
+// ------------------------------------------------------------------------------------------------------
+// V arg-max codes (one byte each) of an item as one LDS word / double word
+template <int V> struct SpCodes;
+template <> struct SpCodes<8> {
+    typedef uint2 W;
+    __device__ static __forceinline__ W pack(const int* c) {
+        return make_uint2((unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16) | ((unsigned)c[3] << 24),
+                          (unsigned)c[4] | ((unsigned)c[5] << 8) | ((unsigned)c[6] << 16) | ((unsigned)c[7] << 24));
+    }
+    __device__ static __forceinline__ int get(const W& w, int e) { return (int)(((e < 4 ? w.x : w.y) >> ((e & 3) * 8)) & 0xffu); }
+};
+template <> struct SpCodes<4> {
+    typedef unsigned W;
+    __device__ static __forceinline__ W pack(const int* c) {
+        return (unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16) | ((unsigned)c[3] << 24);
+    }
+    __device__ static __forceinline__ int get(const W& w, int e) { return (int)((w >> (e * 8)) & 0xffu); }
+};
+#define SP_CG 2
+// Forward: every pool is SEPARABLE — a row pass keeps (row maximum, kx of its first occurrence) per position, a column pass takes the
+// first row whose maximum beats the running one: k + k window taps instead of k * k (the pools are VALU-bound on the compare /
+// select chain: 62 us of lane operations for the three 5x5 pools of BASELINE config 2), and the result is still the FIRST maximum in
+// (ky, kx) scan order with ATen's update rule `v > best || isnan(v)` applied along both passes (a NaN wins and the last one stays,
+// in either formulation; the first in-range tap initialises).
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y1, T* __restrict__ y2,
+                                                            T* __restrict__ y3, int ldy, uint8_t* __restrict__ i1, uint8_t* __restrict__ i2,
+                                                            uint8_t* __restrict__ i3, int H, int W, int Cp, int k) {
+    constexpr int V = ET<T>::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    const int HW = H * W;
+    const int items = HW * SP_CG;
+    uint4* cur = (uint4*)sp_smem;                         // the pool's input, then its output
+    uint4* rmax = cur + items;                            // row maxima
+    typedef SpCodes<V> CW;
+    typename CW::W* rkx = (typename CW::W*)(rmax + items);          // [items] kx of the row maxima, one byte per channel
+    const int cpp = Cp / V;
+    const int n = blockIdx.y;
+    const int cq0 = blockIdx.x * SP_CG;
+    const int p = k / 2;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int cg = it % SP_CG, pix = it / SP_CG;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (cq0 + cg < cpp) v = *(const uint4*)(x + ((size_t)n * HW + pix) * ldx + (cq0 + cg) * V);
+        cur[it] = v;
+    }
+    __syncthreads();
+    T* const ys[3] = {y1, y2, y3};
+    uint8_t* const is[3] = {i1, i2, i3};
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        for (int it = threadIdx.x; it < items; it += 256) {               // row pass
+            const int cg = it % SP_CG, pix = it / SP_CG;
+            const int wo = pix % W, ho = pix / W;
+            float best[V];
+            int bk[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bk[e] = 0; }
+            bool first = true;
+            for (int kx = 0; kx < k; ++kx) {
+                const int iw = wo - p + kx;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float v[V];
+                unpack16<T>(cur[(ho * W + iw) * SP_CG + cg], v);
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bk[e] = kx; }
+                first = false;
+            }
+            rmax[it] = pack16<T>(best);
+            rkx[it] = CW::pack(bk);
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < items; it += 256) {               // column pass
+            const int cg = it % SP_CG, pix = it / SP_CG;
+            const int wo = pix % W, ho = pix / W;
+            float best[V];
+            int bi[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+            bool first = true;
+            for (int ky = 0; ky < k; ++ky) {
+                const int ih = ho - p + ky;
+                if ((unsigned)ih >= (unsigned)H) continue;
+                const int rit = (ih * W + wo) * SP_CG + cg;
+                float v[V];
+                unpack16<T>(rmax[rit], v);
+                const typename CW::W rk = rkx[rit];
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = ky * k + CW::get(rk, e); }
+                first = false;
+            }
+            const uint4 o = pack16<T>(best);
+            if (st < 2) cur[it] = o;
+            if (cq0 + cg < cpp) {
+                const size_t gp = (size_t)n * HW + pix;
+                *(uint4*)(ys[st] + gp * ldy + (cq0 + cg) * V) = o;
+                if (is[st]) *(typename CW::W*)(is[st] + gp * Cp + (cq0 + cg) * V) = CW::pack(bi);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// backward of the chain: g2 = dy2 + mp'(dy3), g1 = dy1 + mp'(g2), dx (+)= mp'(g1); every stage is the gather of maxpool_bwd_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict__ dy1, const T* __restrict__ dy2, const T* __restrict__ dy3,
+                                                            int lddy, const uint8_t* __restrict__ i1, const uint8_t* __restrict__ i2,
+                                                            const uint8_t* __restrict__ i3, T* __restrict__ dx, int lddx, int accumulate,
+                                                            int H, int W, int Cp, int k) {
+    constexpr int V = ET<T>::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    const int HW = H * W;
+    uint4* plane[2] = {(uint4*)sp_smem, (uint4*)sp_smem + (size_t)HW * SP_CG};
+    typedef SpCodes<V> CW;
+    typename CW::W* icode = (typename CW::W*)((uint4*)sp_smem + (size_t)2 * HW * SP_CG);   // [items] arg-max codes of the stage
+    const int cpp = Cp / V;
+    const int n = blockIdx.y;
+    const int cq0 = blockIdx.x * SP_CG;
+    const int p = k / 2;
+    const int items = HW * SP_CG;
+    const T* const dys[3] = {dy3, dy2, dy1};          // gradient that enters stage st from its own output slice
+    const uint8_t* const is[3] = {i3, i2, i1};
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int cg = it % SP_CG, pix = it / SP_CG;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (cq0 + cg < cpp) v = *(const uint4*)(dy3 + ((size_t)n * HW + pix) * lddy + (cq0 + cg) * V);
+        plane[0][it] = v;
+    }
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        // codes of this stage's pool (output positions)
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int cg = it % SP_CG, pix = it / SP_CG;
+            if (cq0 + cg < cpp) icode[it] = *(const typename CW::W*)(is[st] + ((size_t)n * HW + pix) * Cp + (cq0 + cg) * V);
+        }
+        __syncthreads();
+        const uint4* src = plane[st & 1];
+        uint4* dst = plane[(st + 1) & 1];
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int cg = it % SP_CG, pix = it / SP_CG;
+            if (cq0 + cg >= cpp) continue;
+            const int iw = pix % W, ih = pix / W;
+            const size_t gp = (size_t)n * HW + pix;
+            float g[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) g[e] = 0.f;
+            // what the unfused chain finds in the buffer it accumulates into: the next slice's own gradient (always there), or
+            // the previous contents of dx for the last stage
+            if (st < 2) unpack16<T>(*(const uint4*)(dys[st + 1] + gp * lddy + (cq0 + cg) * V), g);
+            else if (accumulate) unpack16<T>(*(const uint4*)(dx + gp * lddx + (cq0 + cg) * V), g);
+            for (int ky = 0; ky < k; ++ky) {
+                const int ho = ih + p - ky;
+                if (ho < 0 || ho >= H) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    const int wo = iw + p - kx;
+                    if (wo < 0 || wo >= W) continue;
+                    const int oit = (ho * W + wo) * SP_CG + cg;
+                    float d[V];
+                    unpack16<T>(src[oit], d);
+                    const typename CW::W cw = icode[oit];
+                    const int code = ky * k + kx;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g[e] += (CW::get(cw, e) == code) ? d[e] : 0.f;
+                }
+            }
+            const uint4 o = pack16<T>(g);
+            if (st < 2) dst[it] = o;
+            else *(uint4*)(dx + gp * lddx + (cq0 + cg) * V) = o;
+        }
+        __syncthreads();
+    }
+}
+
+static inline size_t sppf_smem(int dtype, int H, int W, bool bwd) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    (void)bwd;
+    return (size_t)H * W * SP_CG * (2 * 16 + V);          // forward: input/output plane, row maxima, their kx; backward: two planes, codes
+}
+extern "C" int ydl_sppf_pool_supported(int dtype, int H, int W, int C, int k) {
+    if (dtype != YDL_F32 && dtype != YDL_BF16) return 0;
+    if (k < 1 || k % 2 == 0 || k * k > 255 || H < 1 || W < 1 || C < 1) return 0;
+    return sppf_smem(dtype, H, W, true) <= 64 * 1024 ? 1 : 0;
+}
+extern "C" int ydl_sppf_pool_fwd(int dtype, const void* x, int ldx, void* y1, void* y2, void* y3, int ldy,
+                                 uint8_t* idx1, uint8_t* idx2, uint8_t* idx3, int N, int H, int W, int C, int k, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(ydl_sppf_pool_supported(dtype, H, W, C, k), "plane too large for the LDS-resident form (query ydl_sppf_pool_supported)");
+    YDL_CHECK(x && y1 && y2 && y3 && ldx >= Cp && ldy >= Cp && N >= 1, "bad arguments");
+    YDL_CHECK((idx1 == nullptr) == (idx2 == nullptr) && (idx2 == nullptr) == (idx3 == nullptr), "the three index planes come together");
+    YDL_CHECK(aligned16(x) && aligned16(y1) && aligned16(y2) && aligned16(y3) && ldx % V == 0 && ldy % V == 0, "16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((Cp / V + SP_CG - 1) / SP_CG, N);
+    const size_t smem = sppf_smem(dtype, H, W, false);
+    if (dtype == YDL_F32) sppf_pool_fwd_kernel<float><<<grid, 256, smem, st>>>((const float*)x, ldx, (float*)y1, (float*)y2, (float*)y3, ldy, idx1, idx2, idx3, H, W, Cp, k);
+    else sppf_pool_fwd_kernel<bf16_t><<<grid, 256, smem, st>>>((const bf16_t*)x, ldx, (bf16_t*)y1, (bf16_t*)y2, (bf16_t*)y3, ldy, idx1, idx2, idx3, H, W, Cp, k);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ydl_sppf_pool_bwd(int dtype, const void* dy1, const void* dy2, const void* dy3, int lddy, const uint8_t* idx1,
+                                 const uint8_t* idx2, const uint8_t* idx3, void* dx, int lddx, int accumulate,
+                                 int N, int H, int W, int C, int k, void* stream) {
+    const int V = dtype == YDL_F32 ? 4 : 8;
+    const int Cp = round_up(C, V);
+    YDL_CHECK(ydl_sppf_pool_supported(dtype, H, W, C, k), "plane too large for the LDS-resident form (query ydl_sppf_pool_supported)");
+    YDL_CHECK(dy1 && dy2 && dy3 && idx1 && idx2 && idx3 && dx && lddy >= Cp && lddx >= Cp && N >= 1, "bad arguments");
+    YDL_CHECK(aligned16(dy1) && aligned16(dy2) && aligned16(dy3) && aligned16(dx) && lddy % V == 0 && lddx % V == 0, "16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((Cp / V + SP_CG - 1) / SP_CG, N);
+    const size_t smem = sppf_smem(dtype, H, W, true);
+    if (dtype == YDL_F32) sppf_pool_bwd_kernel<float><<<grid, 256, smem, st>>>((const float*)dy1, (const float*)dy2, (const float*)dy3, lddy, idx1, idx2, idx3, (float*)dx, lddx, accumulate, H, W, Cp, k);
+    else sppf_pool_bwd_kernel<bf16_t><<<grid, 256, smem, st>>>((const bf16_t*)dy1, (const bf16_t*)dy2, (const bf16_t*)dy3, lddy, idx1, idx2, idx3, (bf16_t*)dx, lddx, accumulate, H, W, Cp, k);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // resize
 // ------------------------------------------------------------------------------------------------------
 struct Lin { int i0, i1; float w0, w1; };

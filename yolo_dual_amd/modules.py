@@ -719,9 +719,7 @@ class SPPF(YdlModule):
         c_ = self.c_
         cat = tape.new(x.N, 4 * c_, x.H, x.W)
         s0 = self.cv1._fwd(tape, x, out=cat.slice(0, c_))
-        s1 = tape.maxpool(s0, self.k, 1, self.k // 2, out=cat.slice(c_, 2 * c_))
-        s2 = tape.maxpool(s1, self.k, 1, self.k // 2, out=cat.slice(2 * c_, 3 * c_))
-        tape.maxpool(s2, self.k, 1, self.k // 2, out=cat.slice(3 * c_, 4 * c_))
+        tape.sppf_pools(s0, self.k, [cat.slice(c_, 2 * c_), cat.slice(2 * c_, 3 * c_), cat.slice(3 * c_, 4 * c_)])
         return self.cv2._fwd(tape, cat)
 
 

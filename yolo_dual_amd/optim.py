@@ -163,12 +163,9 @@ class FlatSGDEMA(torch.optim.Optimizer):
         ev.record()
         self._hyper_used[i] = True
 
-    @torch.no_grad()
-    def step_device_hyper(self) -> None:
-        """device half: the same kernels as ``step`` but reading hyper-parameters from ``_hyper_dev`` (capturable)"""
-        st = _stream()
-        pa, ga, ma, ea = self.params_arena, self.grads_arena, self.mom_arena, self.ema_arena
-        use_ema = 1 if ea is not None else 0
+    def _runs(self, commit: bool) -> List[List]:
+        """maximal runs of consecutive slots with identical (touched, group, first-step) state; ``commit`` marks the touched
+        parameters as having a momentum buffer from now on"""
         runs: List[List] = []
         for p, off, n, gi in self._slots:
             touched = bool(getattr(p, "_ydl_touched", False))
@@ -178,9 +175,54 @@ class FlatSGDEMA(torch.optim.Optimizer):
                 runs[-1][2] = off + n
             else:
                 runs.append([key, off, off + n])
-            if touched:
+            if touched and commit:
                 self._has_buf[id(p)] = True
+        return runs
+
+    def _run_rows(self, runs) -> tuple:
+        """rows {offset, n_decay, n_params, n_total, lr index, flags} of ydl_sgd_ema_step_multi"""
+        rows = []
+        for (touched, gi, first), a, b in runs:
+            n = b - a
+            if touched:
+                rows.append((a, n if gi == 0 else 0, n, n, gi, (1 if gi == 0 else 0) | (2 if first else 0)))
+            elif self.ema_arena is not None:
+                rows.append((a, 0, 0, n, 0, 0))
+        if self.ema_arena is not None and self.n_total > self.n_params:
+            rows.append((self.n_params, 0, 0, self.n_total - self.n_params, 0, 0))
+        return tuple(rows)
+
+    def ensure_runs_table(self) -> None:
+        """device table of the CURRENT run structure (as the last backward left the touched flags), created now: call after the
+        warm-up steps and before entering a private pool, next to ``ensure_hyper``"""
+        sig = self._run_rows(self._runs(commit=False))
+        tab = getattr(self, "_runs_dev", None)
+        if sig and (tab is None or tab[0] != sig):
+            self._runs_dev = (sig, torch.tensor(sig, dtype=torch.int64).to(self.params_arena.device))
+
+    @torch.no_grad()
+    def step_device_hyper(self) -> None:
+        """device half: the same kernels as ``step`` but reading hyper-parameters from ``_hyper_dev`` (capturable)"""
+        st = _stream()
+        pa, ga, ma, ea = self.params_arena, self.grads_arena, self.mom_arena, self.ema_arena
+        use_ema = 1 if ea is not None else 0
+        runs = self._runs(commit=True)
         hp = _p(self._hyper_dev)
+        # one launch for all runs.  The table is a persistent device tensor keyed by the run structure (constant once every live
+        # parameter has its momentum buffer); inside a recording / capture pass a NEW table must not be allocated (private pool),
+        # so a miss there takes the per-run launches below
+        rows = self._run_rows(runs)
+        sig = rows
+        tab = getattr(self, "_runs_dev", None)
+        if (tab is None or tab[0] != sig) and rows and L.recorder() is None and not torch.cuda.is_current_stream_capturing():
+            tab = (sig, torch.tensor(rows, dtype=torch.int64).to(pa.device))
+            self._runs_dev = tab
+        if tab is not None and tab[0] == sig:
+            if rows:
+                L.call("ydl_sgd_ema_step_multi", _p(pa), _p(ga), _p(ma), _p(ea) if ea is not None else None, _p(tab[1]), len(rows),
+                       max(r[3] for r in rows), hp, use_ema, st)
+            config.bump_weight_epoch()
+            return
         for (touched, gi, first), a, b in runs:
             n = b - a
             eptr = _p(ea[a:b]) if ea is not None else None

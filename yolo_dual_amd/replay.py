@@ -144,6 +144,7 @@ class ReplayedTrainStep:
         optimizer.ensure_hyper()
         for _ in range(max(warmup, 1)):        # lazily created caches (compute weights, descriptors, bias rows), momentum flags settle
             self._eager_step()
+        optimizer.ensure_runs_table()
         torch.cuda.synchronize()
         self.main = torch.cuda.current_stream()
         self.pool = torch.cuda.MemPool()

@@ -689,6 +689,44 @@ class Tape:
             self.bw.append(bw)
         return out
 
+    def sppf_pools(self, x: Var, k: int, outs: Sequence[Var]) -> Sequence[Var]:
+        """SPPF's chain y1 = mp(x), y2 = mp(y1), y3 = mp(y2) (k x k, stride 1, pad k//2; seg_diceloss_yolov5.py:468-481) into the
+        three given destinations (concat slices): one LDS-resident launch per direction when the plane fits
+        (ydl_sppf_pool_fwd / _bwd, bit-identical to the chain), otherwise three ``maxpool`` calls."""
+        o1, o2, o3 = outs
+        x = self.materialize(x)
+        fused = (k % 2 == 1 and x.aligned() and all(o.aligned() and o.ld == o1.ld and o.dt == x.dt for o in outs)
+                 and all((o.N, o.C, o.H, o.W) == (x.N, x.C, x.H, x.W) for o in outs)
+                 and L.lib().ydl_sppf_pool_supported(x.dt, x.H, x.W, x.C, k))
+        if not fused:
+            s1 = self.maxpool(x, k, 1, k // 2, out=o1)
+            s2 = self.maxpool(s1, k, 1, k // 2, out=o2)
+            s3 = self.maxpool(s2, k, 1, k // 2, out=o3)
+            return s1, s2, s3
+        Cp = round_up(x.C, 4 if x.dt == L.YDL_F32 else 8)
+        n = x.N * x.H * x.W * Cp
+        idx = [torch.empty((n,), dtype=torch.uint8, device=self.device) for _ in range(3)] if self.record else [None] * 3
+        L.call("ydl_sppf_pool_fwd", x.dt, _p(x.t), x.ld, _p(o1.t), _p(o2.t), _p(o3.t), o1.ld, _p(idx[0]), _p(idx[1]), _p(idx[2]),
+               x.N, x.H, x.W, x.C, k, _stream())
+        if self.record:
+            def bw():
+                st = _stream()
+                if all(o.is_set() for o in outs) and x.need:
+                    g1, g2, g3 = (self._gbuf(o) for o in outs)
+                    gx, acc = self.grad_target(x)
+                    L.call("ydl_sppf_pool_bwd", x.dt, _p(g1), _p(g2), _p(g3), o1.ld, _p(idx[0]), _p(idx[1]), _p(idx[2]),
+                           _p(gx), x.ld, acc, x.N, x.H, x.W, x.C, k, st)
+                    return
+                # a slice without a gradient (dead consumer): the chain link by link, as three maxpool closures would run it
+                for src, dst, ix in ((o2, o3, idx[2]), (o1, o2, idx[1]), (x, o1, idx[0])):
+                    if not dst.is_set() or not src.need:
+                        continue
+                    gx, acc = self.grad_target(src)
+                    L.call("ydl_maxpool_bwd", x.dt, _p(self._gbuf(dst)), dst.ld, _p(ix), _p(gx), src.ld, acc,
+                           x.N, x.H, x.W, x.H, x.W, x.C, k, 1, k // 2, st)
+            self.bw.append(bw)
+        return o1, o2, o3
+
     def resize(self, x: Var, Ho: int, Wo: int, mode: int, scale_h: float = 0.0, scale_w: float = 0.0,
                out: Optional[Var] = None) -> Var:
         """mode: L.RESIZE_NEAREST / RESIZE_BILINEAR (align_corners=False) / RESIZE_BILINEAR_AC (True)."""
