@@ -631,12 +631,56 @@ __global__ __launch_bounds__(256) void nchw_to_s2d_kernel(const float* __restric
         }
     }
 }
+// s = 2, C <= 4 (the RGB stem): the two columns of a pixel pair arrive as ONE 8-byte load per (channel, row) — six coalesced loads per
+// thread instead of twelve strided ones — and the channel index arithmetic is compile-time (the generic kernel divides by the
+// run-time C and s per element: 46 us for the 79 MB input of BASELINE config 2)
+template <typename T, int C>
+__global__ __launch_bounds__(256) void nchw_to_s2d2_kernel(const float* __restrict__ src, T* __restrict__ dst, int ldd, int H, int W) {
+    constexpr int V = ET<T>::V;
+    constexpr int Cs = C * 4;
+    static_assert(Cs <= 16, "at most 16 space-to-depth channels");
+    const int n = blockIdx.y;
+    const int Ho = H / 2, Wo = W / 2;
+    const long long HWo = (long long)Ho * Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HWo; i += (long long)gridDim.x * blockDim.x) {
+        const int wo = (int)(i % Wo), ho = (int)(i / Wo);
+        float f[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const float2 v = *(const float2*)(src + (((size_t)n * C + c) * H + (ho * 2 + dy)) * W + wo * 2);
+                f[(dy * 2 + 0) * C + c] = v.x;
+                f[(dy * 2 + 1) * C + c] = v.y;
+            }
+        T* d = dst + ((size_t)n * HWo + i) * ldd;
+        for (int c0 = 0; c0 < ldd; c0 += V) {
+            float g[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) g[e] = 0.f;
+            if (c0 < 16) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) g[e] = c0 == 0 ? f[e] : (c0 == 4 ? f[(4 + e) & 15] : (c0 == 8 ? f[(8 + e) & 15] : f[(12 + e) & 15]));
+            }
+            *(uint4*)(d + c0) = pack16<T>(g);
+        }
+    }
+}
+
 extern "C" int ydl_nchw_to_s2d(int dtype, const float* src, void* dst, int ldd, int N, int C, int H, int W, int s, void* stream) {
     YDL_CHECK(src && dst && s >= 1 && H % s == 0 && W % s == 0 && ldd >= C * s * s && ldd % 8 == 0,
               "H and W must be multiples of s; ldd must cover C*s*s and be a multiple of 8");
     long long HWo = (long long)(H / s) * (W / s);
     dim3 grid((unsigned)((HWo + 255) / 256), N);
     hipStream_t st = (hipStream_t)stream;
+    if (s == 2 && C == 3 && W % 2 == 0 && ((uintptr_t)src & 7) == 0) {
+        if (dtype == YDL_F32) nchw_to_s2d2_kernel<float, 3><<<grid, 256, 0, st>>>(src, (float*)dst, ldd, H, W);
+        else nchw_to_s2d2_kernel<bf16_t, 3><<<grid, 256, 0, st>>>(src, (bf16_t*)dst, ldd, H, W);
+        YDL_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == YDL_F32) nchw_to_s2d_kernel<float><<<grid, 256, 0, st>>>(src, (float*)dst, ldd, C, H, W, s);
     else nchw_to_s2d_kernel<bf16_t><<<grid, 256, 0, st>>>(src, (bf16_t*)dst, ldd, C, H, W, s);
     YDL_LAUNCH_CHECK();

@@ -93,7 +93,16 @@ def refresh_weights(fn: nn.Module, tape: Tape) -> None:
     if convs is None:
         convs = [m for m in fn.modules() if isinstance(m, Conv) and not m.depthwise]
         fn._ydl_convs = convs
-    stale = [m for m in convs if m._wcache.get("key") != m._wkey(tape)]
+        fn._ydl_csp = [m for m in fn.modules() if isinstance(getattr(m, "cv1", None), Conv) and isinstance(getattr(m, "cv2", None), Conv)]
+    # sibling pairs that ran fused last time are prepared as ONE matrix (their masters are adjacent), their members not at all
+    pairs = [b._pair for b in fn._ydl_csp
+             if getattr(b, "_pair", None) is not None and b._pair._wcache.get("key") is not None and b._pair.still_valid()]
+    if pairs:
+        members = {id(m) for pr in pairs for m in (pr.a, pr.b)}
+        units = [m for m in convs if id(m) not in members] + pairs
+    else:
+        units = convs
+    stale = [m for m in units if m._wcache.get("key") != m._wkey(tape)]
     if len(stale) < 2:
         return
     rows, keep = [], []
