@@ -81,6 +81,29 @@ int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w
 /* dx (+)= conv_transpose(dy, wt).  accumulate != 0 adds into dx (gradient fan-in). */
 int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
                    int accumulate, void* stream);
+/* The input gradient with the BatchNorm backward's REDUCE pass of the layer(s) that produced the convolution's input fused into
+ * its epilogue (throughput mode: replica sums, see ydl_bn_act_bwd_sums).  dx — the gradient this call completes, i.e. the `dout` of
+ * those layers — is still in registers when it is stored: the epilogue reads the producers' saved pre-activations y once,
+ * forms dz = dx * act'(y*scale + shift) and adds (sum dz, sum dz*xhat) per channel into sums[i] = [YDL_BN_REPLICAS][2][cp[i]]
+ * (zeroed by the caller), so ydl_bn_act_bwd_apply_sums can follow without the reduce launch and its second read of dx.
+ * Valid only when this call is the LAST writer of dx (accumulate != 0 is fine: the stored sum is what is reduced).
+ * Up to two channel segments [c0, c1) of dx (multiples of 8), each with its own producer: a channel concat of two layers.
+ * Per-segment pointers are at the segment's channel 0 (= channel c0 of dx).  act: YDL_ACT_NONE or YDL_ACT_SILU.
+ * ydl_conv_dgrad_bnred_supported: 1 when this geometry runs on a kernel whose epilogue has the fused form (bf16 ring kernels),
+ * else use ydl_conv_dgrad + ydl_bn_act_bwd_sums. */
+typedef struct {
+    int nseg;
+    int c0[2], c1[2], ldy[2], cp[2], act[2];
+    const void* y[2];
+    const float* scale[2];
+    const float* shift[2];
+    const float* mean[2];
+    const float* invstd[2];
+    float* sums[2];
+} ydl_bnred;
+int ydl_conv_dgrad_bnred_supported(const ydl_conv_geom* g, int dtype);
+int ydl_conv_dgrad_bnred(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
+                         int accumulate, const ydl_bnred* red, void* stream);
 /* dw[Cout][k*k][Cin_p] (f32) += sum over pixels dy^T * im2col(x).  dw must be zeroed (or hold the running
  * sum for gradient accumulation) before the call: split-K blocks add with f32 atomics. */
 int ydl_conv_wgrad(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, float* dw, void* stream);
@@ -153,6 +176,12 @@ int ydl_bn_act_bwd_sums(int dtype, const void* y, int ldy, const void* dout, int
                         int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
                         float* dgamma, float* dbeta, int accumulate_param_grads,
                         float* sums, int64_t npix, int C, int Cp, void* stream);
+/* the apply pass alone: sums already hold (sum dz, sum dz*xhat) of this tensor (ydl_conv_dgrad_bnred) */
+int ydl_bn_act_bwd_apply_sums(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                              const float* mean, const float* invstd, const float* scale, const float* shift,
+                              int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                              float* dgamma, float* dbeta, int accumulate_param_grads,
+                              float* sums, int64_t npix, int C, int Cp, void* stream);
 
 /* ---- spatial ops (NHWC, channel-vectorised) -------------------------------------------------------- */
 /* max pool (k,s,p), -inf padding; idx (uint8 window offset of the arg-max, first max in scan order) is
@@ -352,7 +381,7 @@ void ydl_replay_destroy(ydl_replay* r);
 int ydl_replay_fn_count(void);
 const char* ydl_replay_fn_name(int fn);
 /* append one call: args = the entry point's parameters before `stream`, one 8-byte slot each (integers and pointers as
- * int64, floats as the bits of a double; a ydl_conv_geom* slot holds a HOST pointer whose struct is copied) */
+ * int64, floats as the bits of a double; a ydl_conv_geom* / ydl_bnred* slot holds a HOST pointer whose struct is copied) */
 int ydl_replay_add_call(ydl_replay* r, int fn, const int64_t* args, int nargs, int stream_slot);
 /* cross-stream edge: hipEventRecord(event[id], stream[slot]) / hipStreamWaitEvent(stream[slot], event[id]) */
 int ydl_replay_add_event_record(ydl_replay* r, int event_id, int stream_slot);

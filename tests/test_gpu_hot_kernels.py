@@ -388,3 +388,70 @@ def test_sppf_pool_chain_in_one_launch_equals_three_maxpools(dtype, N, C, H, W, 
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
     assert torch.equal(res[0][2], res[1][2])
+
+
+BNRED = [("ring9_two_segments", 4, 128, 128, 3, 1, 80, 80, [(0, 64, 1), (64, 128, 0)], 0),
+         ("ring13_one_segment_accumulate", 8, 64, 128, 3, 1, 160, 160, [(0, 64, 1)], 1),
+         ("ring7_partial_cover", 16, 128, 512, 1, 1, 48, 48, [(64, 128, 1)], 0),
+         ("ring13_stride2_classes", 4, 64, 128, 3, 2, 160, 160, [(0, 64, 1)], 0),
+         ("ring7_persistent", 16, 128, 64, 3, 1, 160, 160, [(0, 128, 1)], 0)]
+
+
+@pytest.mark.parametrize("case", BNRED, ids=[c[0] for c in BNRED])
+def test_dgrad_with_fused_bn_backward_reduce(case):
+    """ydl_conv_dgrad_bnred: the input gradient equals ydl_conv_dgrad's bit for bit, and the per-channel (sum dz, sum dz*xhat) the
+    epilogue adds into the replica rows equal the BatchNorm-backward reduce of that stored gradient (float64 restatement of
+    bn_bwd_reduce: dz = dout * silu'(y*scale + shift), xhat = (y - mean) * invstd) — one and two producer segments, accumulate,
+    a segment covering half of the channels, the stride-2 parity classes, the persistent ring kernel"""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    tag, N, Cin, Cout, k, s_, Hi, Wi, segs, acc = case
+    p = k // 2
+    Ho, Wo = (Hi + 2 * p - k) // s_ + 1, (Wi + 2 * p - k) // s_ + 1
+    dev = "cuda"
+    gen = torch.Generator(dev).manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, device=dev, generator=gen)
+    dy = rnd(N, Ho, Wo, Cout).bfloat16()
+    wt = (rnd(Cin, k * k, Cout) * 0.05).bfloat16()
+    g = L.ConvGeom(N, Hi, Wi, Cin, Ho, Wo, Cout, k, s_, p, Cin, Cout, 0)
+    gp = ctypes.byref(g)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.lib().ydl_conv_dgrad_bnred_supported(gp, L.YDL_BF16) == 1, tag
+    base = (rnd(N, Hi, Wi, Cin) * 0.5).bfloat16() if acc else torch.zeros(N, Hi, Wi, Cin, device=dev, dtype=torch.bfloat16)
+    dx_ref = base.clone()
+    L.call("ydl_conv_dgrad", gp, L.YDL_BF16, P(dy), P(wt), P(dx_ref), acc, st)
+    plain = L.last_kernel(1)
+    red = L.BnRed()
+    red.nseg = len(segs)
+    keep = []
+    for i, (c0, c1, act) in enumerate(segs):
+        cw = c1 - c0
+        y = rnd(N, Hi, Wi, cw).bfloat16()
+        sc, sf = rnd(cw) * 0.5 + 1.0, rnd(cw) * 0.3
+        mu, inv = rnd(cw) * 0.2, rnd(cw).abs() + 0.5
+        sums = torch.zeros(L.BN_REPLICAS * 2 * cw, device=dev)
+        red.c0[i], red.c1[i], red.ldy[i], red.cp[i], red.act[i] = c0, c1, cw, cw, act
+        red.y[i], red.scale[i], red.shift[i] = y.data_ptr(), sc.data_ptr(), sf.data_ptr()
+        red.mean[i], red.invstd[i], red.sums[i] = mu.data_ptr(), inv.data_ptr(), sums.data_ptr()
+        keep.append((y, sc, sf, mu, inv, sums))
+    dx = base.clone()
+    L.call("ydl_conv_dgrad_bnred", gp, L.YDL_BF16, P(dy), P(wt), P(dx), acc, ctypes.byref(red), st)
+    fusedk = L.last_kernel(1)
+    torch.cuda.synchronize()
+    assert "bnred" in fusedk and fusedk.replace(",bnred", "") == plain.replace(":persistent", ""), (plain, fusedk)
+    if tag == "ring7_persistent":
+        assert plain.endswith(":persistent"), plain        # (the fused form runs one tile per CTA: register budget)
+    assert torch.equal(dx, dx_ref)
+    for (c0, c1, act), (y, sc, sf, mu, inv, sums) in zip(segs, keep):
+        cw = c1 - c0
+        d = dx_ref[..., c0:c1].double().reshape(-1, cw)
+        yy = y.double().reshape(-1, cw)
+        z = yy * sc.double() + sf.double()
+        sg = torch.sigmoid(z)
+        dz = d * (sg * (1 + z * (1 - sg))) if act else d
+        xh = (yy - mu.double()) * inv.double()
+        ref = torch.stack([dz.sum(0), (dz * xh).sum(0)])
+        got = sums.view(L.BN_REPLICAS, 2, cw).double().sum(0)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 2e-4, (tag, c0, err)

@@ -524,3 +524,107 @@ def test_config5_size_yolov9():
         opt.step()
         losses.append(float(items[0]))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("cfg_name,cls", [("yolov5_seg.yaml", "YOLOv5Seg"), ("yolov8_seg.yaml", "YOLOv8Seg")])
+def test_bn_backward_reduce_fused_into_the_last_dgrad(cfg_name, cls):
+    """throughput mode: the BatchNorm backward's reduce pass runs in the epilogue of the dgrad that writes the layer's output gradient
+    last (ydl_conv_dgrad_bnred + ydl_bn_act_bwd_apply_sums, Tape._try_bnred) instead of as its own launch.  Same gradients as the
+    two-launch form to the run-to-run noise of that form itself (f32 atomics in both), on a whole model with shortcuts, sibling
+    pairs, concat slices and residual aliasing; and the fused entry points did run."""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd import config
+    ydl.set_compute_dtype("bf16")
+    real_call = L.call
+    counts = {}
+
+    def counting(name, *a):
+        counts[name] = counts.get(name, 0) + 1
+        return real_call(name, *a)
+    grads = {}
+    try:
+        for tag, fuse in (("two_a", False), ("two_b", False), ("fused", True)):
+            config.set_bn_bwd_fuse(fuse)
+            m = getattr(ydl, cls)(_cfg(cfg_name, {"C3_DCN": "C3", "C2f_DCN": "C2f"}))
+            m.img_size = [256, 256]
+            sd = m.state_dict()
+            fill_state_dict(sd, 5, bn_stats=False)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            opt = ydl.FlatSGDEMA(m, lr=0.01, momentum=0.937, weight_decay=5e-4)
+            crit = ydl.SegmentationLoss(12, 0.0, CW, "dice", sync=False)
+            gen = torch.Generator("cuda").manual_seed(3)
+            x = torch.rand(8, 3, 256, 256, device="cuda", generator=gen)
+            t = torch.randint(0, 12, (8, 256, 256), device="cuda", generator=gen)
+            opt.zero_grad()
+            counts.clear()
+            L.call = counting
+            try:
+                total, _items = crit(m(x), t)
+                total.backward()
+            finally:
+                L.call = real_call
+            torch.cuda.synchronize()
+            grads[tag] = (opt.grads_arena.detach().float().cpu().clone(), dict(counts))
+        n_fused = grads["fused"][1].get("ydl_conv_dgrad_bnred", 0)
+        n_apply = grads["fused"][1].get("ydl_bn_act_bwd_apply_sums", 0)
+        n_full = grads["fused"][1].get("ydl_bn_act_bwd_sums", 0)
+        print(f"[bnred {cls}] fused dgrads {n_fused}, apply-only BN backward {n_apply}, two-launch BN backward {n_full}")
+        assert n_fused >= 5 and n_apply >= n_fused, grads["fused"][1]
+        assert grads["two_a"][1].get("ydl_conv_dgrad_bnred", 0) == 0
+        noise = l2_err(grads["two_b"][0], grads["two_a"][0])
+        got = l2_err(grads["fused"][0], grads["two_a"][0])
+        print(f"[bnred {cls}] gradient arena: fused vs two-launch {got:.2e}, two-launch vs itself {noise:.2e}")
+        assert got <= 3 * noise + 1e-4, (got, noise)
+    finally:
+        L.call = real_call
+        config.set_bn_bwd_fuse(False)
+        ydl.set_compute_dtype("bf16")
+
+
+def test_bn_backward_reduce_fused_in_blocks():
+    """the same comparison where it is sharp: single blocks (one to three BatchNorm layers between the seeded gradient and the input),
+    so that bf16 rounding chaos cannot hide an error — input gradient and every parameter gradient of the fused form against the
+    two-launch form, and the fused entry point must have run"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd import config
+    ydl.set_compute_dtype("bf16")
+    real_call = L.call
+    counts = {}
+
+    def counting(name, *a):
+        counts[name] = counts.get(name, 0) + 1
+        return real_call(name, *a)
+    try:
+        for make, shape in ((lambda: ydl.C3(128, 128, 1), (8, 128, 80, 80)), (lambda: ydl.C3(128, 128, 2, False), (4, 128, 96, 96)),
+                            (lambda: ydl.Bottleneck(128, 128), (8, 128, 64, 64)), (lambda: ydl.C2f(128, 128, 1), (8, 128, 48, 48))):
+            res = []
+            for fuse in (False, True):
+                config.set_bn_bwd_fuse(fuse)
+                m = make()
+                sd = m.state_dict()
+                fill_state_dict(sd, 11, bn_stats=True)
+                m.load_state_dict(sd)
+                m = m.cuda().train()
+                opt = ydl.FlatSGDEMA(m, lr=0.01)
+                x = torch.randn(*shape, device="cuda", generator=torch.Generator("cuda").manual_seed(2)).requires_grad_(True)
+                opt.zero_grad()
+                counts.clear()
+                L.call = counting
+                try:
+                    out = m(x)
+                    (out * torch.randn(out.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(3))).sum().backward()
+                finally:
+                    L.call = real_call
+                res.append(([x.grad.float().cpu()] + [p.grad.detach().float().clone().cpu() for p in m.parameters()], dict(counts)))
+            assert res[1][1].get("ydl_conv_dgrad_bnred", 0) >= 1, (shape, res[1][1])
+            assert res[0][1].get("ydl_conv_dgrad_bnred", 0) == 0
+            worst = max(l2_err(b, a) for a, b in zip(res[0][0], res[1][0]))
+            print(f"[bnred block {shape}] fused dgrads {res[1][1].get('ydl_conv_dgrad_bnred', 0)}, worst gradient difference {worst:.2e}")
+            assert worst < 1.5e-2, (shape, worst)
+    finally:
+        L.call = real_call
+        config.set_bn_bwd_fuse(False)
+        ydl.set_compute_dtype("bf16")

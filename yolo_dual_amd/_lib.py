@@ -24,8 +24,16 @@ class ConvGeom(C.Structure):
                 ("ldx", C.c_int), ("ldy", C.c_int), ("ldw", C.c_int)]
 
 
+class BnRed(C.Structure):
+    """ydl_bnred of ydl.h: up to two channel segments of a gradient whose BatchNorm-backward reduce pass runs in the dgrad epilogue"""
+    _fields_ = [("nseg", C.c_int), ("c0", C.c_int * 2), ("c1", C.c_int * 2), ("ldy", C.c_int * 2), ("cp", C.c_int * 2), ("act", C.c_int * 2),
+                ("y", C.c_void_p * 2), ("scale", C.c_void_p * 2), ("shift", C.c_void_p * 2), ("mean", C.c_void_p * 2),
+                ("invstd", C.c_void_p * 2), ("sums", C.c_void_p * 2)]
+
+
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 _G = C.POINTER(ConvGeom)
+_R = C.POINTER(BnRed)
 
 # name -> (restype, argtypes); mirrors include/ydl.h one to one
 SIGNATURES = {
@@ -40,6 +48,8 @@ SIGNATURES = {
     "ydl_conv_fwd": (_i, [_G, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_fwd_sums": (_i, [_G, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_dgrad": (_i, [_G, _i, _vp, _vp, _vp, _i, _vp]),
+    "ydl_conv_dgrad_bnred_supported": (_i, [_G, _i]),
+    "ydl_conv_dgrad_bnred": (_i, [_G, _i, _vp, _vp, _vp, _i, _R, _vp]),
     "ydl_conv_wgrad": (_i, [_G, _i, _vp, _vp, _vp, _vp]),
     "ydl_conv_wgrad_ws_bytes": (_i64, [_G, _i]),
     "ydl_conv_wgrad_det": (_i, [_G, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -52,6 +62,8 @@ SIGNATURES = {
     "ydl_bn_act_fwd_sums": (_i, [_i, _vp, _i, _vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i,
                                  _i64, _i, _i, _vp]),
     "ydl_bn_act_bwd_sums": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i,
+                                 _vp]),
+    "ydl_bn_act_bwd_apply_sums": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i,
                                  _vp]),
     "ydl_bn_bwd_ws_bytes": (_i64, [_i64, _i]),
     "ydl_bn_act_bwd": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i,
@@ -231,12 +243,12 @@ def call(name: str, *args):
     check(getattr(lib(), name)(*args), name)
     e1.record()
     g = None
-    if name in ("ydl_conv_fwd", "ydl_conv_fwd_sums", "ydl_conv_dgrad", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
+    if name in ("ydl_conv_fwd", "ydl_conv_fwd_sums", "ydl_conv_dgrad", "ydl_conv_dgrad_bnred", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
         src = args[0]._obj
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
         g._es = 4 if args[1] == YDL_F32 else 2
-        g._kernel = last_kernel(1 if name == "ydl_conv_dgrad" else 2 if "wgrad" in name else 0)
-        g._acc = int(args[5]) if name == "ydl_conv_dgrad" else int(args[6]) if name.startswith("ydl_conv_fwd") else 0
+        g._kernel = last_kernel(1 if "dgrad" in name else 2 if "wgrad" in name else 0)
+        g._acc = int(args[5]) if "dgrad" in name else int(args[6]) if name.startswith("ydl_conv_fwd") else 0
     elif name == "ydl_bn_act_fwd":          # algorithmic bytes: y (+ residual) read once, out written once
         es = 4 if args[0] == YDL_F32 else 2
         g = float(args[11]) * args[12] * es * (2 + (1 if args[7] else 0))

@@ -102,6 +102,18 @@ def set_bn_sums(on: bool) -> None:
     _STATE["bn_sums"] = bool(on)
 
 
+def bn_bwd_fuse() -> bool:
+    """with replica sums: run the BatchNorm backward's reduce pass in the epilogue of the dgrad that writes the layer's output
+    gradient last (ydl_conv_dgrad_bnred) instead of as its own launch.  OFF by default: measured on BASELINE config 2 the fused
+    dgrads take 1.4 ms instead of 0.71 (the epilogue's SiLU' arithmetic lands on compute-bound kernels) for 0.27 ms less BatchNorm
+    time, 2152 against 2245 images/s.  YDL_BN_FUSE=1 / set_bn_bwd_fuse(True) switches it on"""
+    return _STATE.setdefault("bn_bwd_fuse", os.environ.get("YDL_BN_FUSE", "0") != "0")
+
+
+def set_bn_bwd_fuse(on: bool) -> None:
+    _STATE["bn_bwd_fuse"] = bool(on)
+
+
 def replicated_loss() -> bool:
     """SegmentationLoss evaluates a nearest-replicated prediction per stored pixel (ydl_seg_loss_rep_*)"""
     return _STATE["replicated_loss"]

@@ -816,11 +816,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
     }
 }
 
-extern "C" int ydl_bn_act_bwd_sums(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
-                                   const float* mean, const float* invstd, const float* scale, const float* shift,
-                                   int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
-                                   float* dgamma, float* dbeta, int accumulate_param_grads,
-                                   float* sums, int64_t npix, int C, int Cp, void* stream) {
+static int bn_act_bwd_sums_impl(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                                const float* mean, const float* invstd, const float* scale, const float* shift,
+                                int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                                float* dgamma, float* dbeta, int accumulate_param_grads,
+                                float* sums, int64_t npix, int C, int Cp, void* stream, bool with_reduce) {
     const int dres_acc = (res_mode & YDL_RES_GRAD_ACCUMULATE) ? 1 : 0;
     const int rmode = res_mode & 15;
     YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16, "bad dtype");
@@ -842,8 +842,9 @@ extern "C" int ydl_bn_act_bwd_sums(int dtype, const void* y, int ldy, const void
                                                            accumulate_param_grads, npix, C, Cp)
 #define YDL_BS_LAUNCH(T, A)                                                                                                        \
     do {                                                                                                                           \
-        bn_bwd_reduce_sums_kernel<T, A><<<g1, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale,    \
-                                                            shift, mean, invstd, sums, npix, Cp);                                 \
+        if (with_reduce)                                                                                                           \
+            bn_bwd_reduce_sums_kernel<T, A><<<g1, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale, \
+                                                                shift, mean, invstd, sums, npix, Cp);                              \
         if (resm == 0) YDL_BS_APPLY(T, A, 0);                                                                                      \
         else if (resm == 1) YDL_BS_APPLY(T, A, 1);                                                                                 \
         else YDL_BS_APPLY(T, A, 2);                                                                                                \
@@ -858,4 +859,21 @@ extern "C" int ydl_bn_act_bwd_sums(int dtype, const void* y, int ldy, const void
     else YDL_BS_ACT(bf16_t);
     YDL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int ydl_bn_act_bwd_sums(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                                   const float* mean, const float* invstd, const float* scale, const float* shift,
+                                   int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                                   float* dgamma, float* dbeta, int accumulate_param_grads,
+                                   float* sums, int64_t npix, int C, int Cp, void* stream) {
+    return bn_act_bwd_sums_impl(dtype, y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, res_mode, act, dy, lddy, dres, lddr,
+                                dgamma, dbeta, accumulate_param_grads, sums, npix, C, Cp, stream, true);
+}
+extern "C" int ydl_bn_act_bwd_apply_sums(int dtype, const void* y, int ldy, const void* dout, int lddo, const void* out, int ldo,
+                                         const float* mean, const float* invstd, const float* scale, const float* shift,
+                                         int res_mode, int act, void* dy, int lddy, void* dres, int lddr,
+                                         float* dgamma, float* dbeta, int accumulate_param_grads,
+                                         float* sums, int64_t npix, int C, int Cp, void* stream) {
+    return bn_act_bwd_sums_impl(dtype, y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, res_mode, act, dy, lddy, dres, lddr,
+                                dgamma, dbeta, accumulate_param_grads, sums, npix, C, Cp, stream, false);
 }

@@ -68,6 +68,26 @@ __device__ __forceinline__ float sigmoid_f(float z) {
 }
 __device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
 
+// BatchNorm backward, per 16-byte bf16 chunk: dz = dout * act'(y*scale + shift), xhat = (y - mean) * invstd (bn.hip: dz_xhat_q;
+// also used by the convolution epilogues that fuse the reduce pass: ydl_conv_dgrad_bnred)
+__device__ __forceinline__ void bn_dz_xhat_bf16x8(const uint4& yq, const uint4& dq, const float* sc, const float* sf, const float* mu,
+                                                  const float* is, bool silu, float* dz, float* xh) {
+    float yv[8], dv[8];
+    unpack16<bf16_t>(yq, yv);
+    unpack16<bf16_t>(dq, dv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float z = yv[e] * sc[e] + sf[e];
+        float d = dv[e];
+        if (silu) {
+            const float sg = sigmoid_f(z);
+            d *= sg * (1.f + z * (1.f - sg));
+        }
+        dz[e] = d;
+        xh[e] = (yv[e] - mu[e]) * is[e];
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -51,6 +51,7 @@ struct IgemmArgs {
                                //                    1 = pixel tiles of one channel tile are neighbours (weight slab stays in L2)
     signed char dh[MAXTAPS], dw[MAXTAPS];
     unsigned char wt[MAXTAPS];
+    ydl_bnred br;              // nseg > 0: the ring epilogue also runs the BatchNorm-backward reduce of the producers of C (dgrad only)
 };
 
 template <typename T> struct Mma;
@@ -475,10 +476,25 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const IgemmArgs p) {
 //    transposing butterfly (each stage halves the live values) and over the WP pixel waves through LDS — same [grid_m][2][C]
 //    (sum, M2) contract as igemm_epilogue, one barrier instead of four.
 // ------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int NW, int WP>
+// RED: the fused BatchNorm-backward reduce; scoef = LDS table [BN][4] (scale, shift, mean, invstd) of the tile's channels, zeros
+// outside the segments (br_fill_coef)
+template <int BN>
+__device__ __forceinline__ void br_fill_coef(const IgemmArgs& p, float* scoef, int n0, int t) {
+    if (t < BN) {
+        const int c = n0 + t;
+        const int sgm = (p.br.nseg > 1 && c >= p.br.c0[1]) ? 1 : 0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c >= p.br.c0[sgm] && c < p.br.c1[sgm]) {
+            const int cl = c - p.br.c0[sgm];
+            v = make_float4(p.br.scale[sgm][cl], p.br.shift[sgm][cl], p.br.mean[sgm][cl], p.br.invstd[sgm][cl]);
+        }
+        *(float4*)(scoef + t * 4) = v;
+    }
+}
+template <int BM, int BN, int NW, int WP, bool RED = false>
 __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)[(BN / (NW / WP)) / 16][BM / (16 * WP)],
                                                 unsigned char* smem, int m0, int n0, int mtile, int c_M, int c_Wg, int c_Hg,
-                                                int c_h0, int c_w0) {
+                                                int c_h0, int c_w0, const float* scoef = nullptr) {
     using T = bf16_t;
     constexpr int WN = NW / WP;
     constexpr int BNW = BN / WN;
@@ -538,13 +554,101 @@ __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)
     {
         const int cq = t % CPR, r0 = t / CPR;
         const int co = n0 + cq * 8;
+        // fused BatchNorm-backward reduce (ydl_conv_dgrad_bnred): this thread's 8 channels belong to one producer segment; the stored
+        // (bf16-rounded) gradient is what the stand-alone reduce pass would read
+        const bool br_on = RED && p.br.nseg > 0;       // RED instantiations only: the reduce costs registers the plain kernels must not pay
+        if (!br_on) {
 #pragma unroll
-        for (int i = 0; i < BM / RPS; ++i) {
-            const int row = r0 + i * RPS;
-            const int m = m0 + row;
-            if (m < c_M && co < p.Cst) {
-                const uint4 v = *(const uint4*)(smem + row * ORB + ((cq ^ (row & (CPR - 1) & 15)) << 4));
-                *(uint4*)(Cg + (dense ? (size_t)m : pixel_of(m)) * p.ldc + co) = v;
+            for (int i = 0; i < BM / RPS; ++i) {
+                const int row = r0 + i * RPS;
+                const int m = m0 + row;
+                if (m < c_M && co < p.Cst) {
+                    const uint4 v = *(const uint4*)(smem + row * ORB + ((cq ^ (row & (CPR - 1) & 15)) << 4));
+                    *(uint4*)(Cg + (dense ? (size_t)m : pixel_of(m)) * p.ldc + co) = v;
+                }
+            }
+        }
+        float sb[8], sg[8];
+        if (br_on) {
+            bool br_live = false;
+            const T* by = nullptr;
+            int bldy = 0;
+            bool bsilu = false;
+            {
+                const int sgm = (p.br.nseg > 1 && co >= p.br.c0[1]) ? 1 : 0;
+                br_live = co >= p.br.c0[sgm] && co < p.br.c1[sgm];
+                if (br_live) {
+                    by = (const T*)p.br.y[sgm] + (co - p.br.c0[sgm]);
+                    bldy = p.br.ldy[sgm];
+                    bsilu = p.br.act[sgm] == YDL_ACT_SILU;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sb[e] = 0.f; sg[e] = 0.f; }
+            // all of the thread's y rows are requested before the first is used (one memory round trip, not one per row)
+            int pixs[BM / RPS];                            // (< 2^31 pixels: check_geom)
+            uint4 yq[BM / RPS];
+#pragma unroll
+            for (int i = 0; i < BM / RPS; ++i) {
+                const int m = m0 + r0 + i * RPS;
+                const bool ok = m < c_M && co < p.Cst;
+                pixs[i] = ok ? (dense ? m : (int)pixel_of(m)) : 0;
+                yq[i] = (ok && br_live) ? *(const uint4*)(by + (size_t)pixs[i] * bldy) : make_uint4(0, 0, 0, 0);
+            }
+            const float* cfp = scoef + cq * 32;            // this thread's 8 channels x (scale, shift, mean, invstd)
+#pragma unroll
+            for (int i = 0; i < BM / RPS; ++i) {
+                const int row = r0 + i * RPS;
+                const int m = m0 + row;
+                if (m < c_M && co < p.Cst) {
+                    const uint4 v = *(const uint4*)(smem + row * ORB + ((cq ^ (row & (CPR - 1) & 15)) << 4));
+                    *(uint4*)(Cg + (size_t)pixs[i] * p.ldc + co) = v;
+                    if (br_live) {
+                        float yv[8], dz[8];
+                        unpack16<T>(yq[i], yv);
+                        unpack16<T>(v, dz);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float4 c4 = *(const float4*)(cfp + e * 4);
+                            if (bsilu) {
+                                const float zz = yv[e] * c4.x + c4.y;
+                                const float sgd = sigmoid_f(zz);
+                                dz[e] *= sgd * (1.f + zz * (1.f - sgd));
+                            }
+                            sb[e] += dz[e];
+                            sg[e] += dz[e] * ((yv[e] - c4.z) * c4.w);
+                        }
+                    }
+                }
+            }
+        }
+        if (br_on) {
+            // lanes of a wave that share the channel chunk, then the NW waves through the (now free) scratch, then one add per channel
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int o = CPR; o < 64; o <<= 1) { sb[e] += __shfl_xor(sb[e], o, 64); sg[e] += __shfl_xor(sg[e], o, 64); }
+            __syncthreads();                               // every thread has read its part of the transposed tile
+            float* sred = (float*)smem;                    // [NW][BN][2]
+            if (lane < CPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sred[((wave * BN) + cq * 8 + e) * 2] = sb[e];
+                    sred[((wave * BN) + cq * 8 + e) * 2 + 1] = sg[e];
+                }
+            }
+            __syncthreads();
+            if (t < BN) {
+                const int c = n0 + t;
+                const int sgm = (p.br.nseg > 1 && c >= p.br.c0[1]) ? 1 : 0;
+                if (c >= p.br.c0[sgm] && c < p.br.c1[sgm]) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) { a += sred[(w * BN + t) * 2]; b += sred[(w * BN + t) * 2 + 1]; }
+                    float* dst = p.br.sums[sgm] + (size_t)(mtile & (YDL_BN_REPLICAS - 1)) * 2 * p.br.cp[sgm];
+                    atomicAdd(dst + (c - p.br.c0[sgm]), a);
+                    atomicAdd(dst + p.br.cp[sgm] + (c - p.br.c0[sgm]), b);
+                }
             }
         }
     }
@@ -679,8 +783,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NW, int WP, int S>
-__global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
+template <int BM, int BN, int NW, int WP, int S, bool RED = false>
+__global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const IgemmArgs p) {
     using T = bf16_t;
     constexpr int ES = 2;
     constexpr int RPP = NW * 8;                 // tile rows covered by one DMA pass of the CTA (one wave = 8 rows)
@@ -726,6 +830,8 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
         sTapB[t] = db;
         sTapD[t] = dd;
     }
+    float* const sCoef = (float*)(sTapD + MAXTAPS);      // RED: [BN][4] BatchNorm coefficients of this tile's channels
+    if constexpr (RED) br_fill_coef<BN>(p, sCoef, n0, t);
     __syncthreads();   // tap tables visible (no DMA is in flight yet)
 
     // this thread's DMA slot: row r of each pass, 16-byte slot qs; it fetches the logical chunk q = qs ^ swizzle(r)
@@ -873,7 +979,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
         if (sink == 123.456f) ((float*)p.C)[0] = sink;
         return;
     }
-    igemm2_epilogue<BM, BN, NW, WP>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0);
+    igemm2_epilogue<BM, BN, NW, WP, RED>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0, sCoef);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -889,7 +995,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmArgs p) {
 // Tile order: linear index = blockIdx.x + j * gridDim.x, mapped through xcd_remap over ALL tiles: with a grid that is a multiple
 // of 8 a CTA keeps drawing from its own XCD's contiguous tile range.
 // ------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int NW, int WP>
+template <int BM, int BN, int NW, int WP, bool RED = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void igemm2p_kernel(const IgemmArgs p) {
     using T = bf16_t;
     constexpr int ES = 2;
@@ -908,6 +1014,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void igemm2p_kernel(const IgemmArg
     int* sTapB = sTapA + MAXTAPS;
     int* sTapD = sTapB + MAXTAPS;
 
+    float* const sCoef = (float*)(sTapD + MAXTAPS);      // RED: [BN][4] BatchNorm coefficients of the current tile's channels
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1080,6 +1187,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void igemm2p_kernel(const IgemmArg
                 for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
         };
         wait_vm_barrier<0>();              // step 0 landed everywhere; everyone is past the previous tile's epilogue
+        if constexpr (RED) br_fill_coef<BN>(p, sCoef, cur.n0, t);      // read again only after the K loop's barriers
         issue(par ^ 1);                    // step 1
         rdfrag(par, 0, af0, bf0);
         for (int kk = 0; kk < nk; ++kk) {
@@ -1099,7 +1207,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void igemm2p_kernel(const IgemmArg
         // every wave has its last fragments in registers before the scratch stage is overwritten (no vmcnt wait: the next tile's DMAs
         // stay in flight through the epilogue)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        igemm2_epilogue<BM, BN, NW, WP>(p, acc, smem + sl * STAGE, cur.m0, cur.n0, cur.mtile, cur.M, cur.Wg, cur.Hg, cur.h0, cur.w0);
+        igemm2_epilogue<BM, BN, NW, WP, RED>(p, acc, smem + sl * STAGE, cur.m0, cur.n0, cur.mtile, cur.M, cur.Wg, cur.Hg, cur.h0, cur.w0, sCoef);
         cur = nxt;
     }
     wait_vm_barrier<0>();              // trailing (all-zero) DMAs land before the CTA's LDS goes away
@@ -1624,7 +1732,7 @@ struct TileCfg { int BM, BN; int ring; };     // ring != 0: igemm2_kernel (bf16 
 static int g_ring_enabled = 1;
 static int g_ring_persist = 1;
 
-template <int BM, int BN, int NW, int WP, int S>
+template <int BM, int BN, int NW, int WP, int S, bool RED = false>
 static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
     a.grid_n = (a.Cst + BN - 1) / BN;
     int mtiles = (a.M + BM - 1) / BM;
@@ -1651,9 +1759,9 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
         static const int dbg = getenv("YDL_RING_DBG") ? atoi(getenv("YDL_RING_DBG")) : 0;
         a.dbg = dbg;
     }
-    const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
+    const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int) + (RED ? BN * 16 : 0);
     static const std::string nm = std::string("igemm2_kernel<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
-                                  std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + ">";
+                                  std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + (RED ? ",bnred>" : ">");
     if constexpr (S == 2) {
         // persistent form (igemm2p_kernel): worth it when a CTA gets more than one tile; needs n_k >= 2 in every class
         static const int persist = getenv("YDL_RING_PERSIST") ? atoi(getenv("YDL_RING_PERSIST")) : 1;
@@ -1661,10 +1769,10 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
         int min_taps = a.ntaps;
         if (a.ncls > 1) { min_taps = 1 << 30; for (int c = 0; c < a.ncls; ++c) min_taps = min(min_taps, a.cls_ntaps[c]); }
         static int per_cu = -1;                  // resident CTAs per CU of this instantiation (registers and LDS)
-        YDL_SET_MAX_LDS((igemm2p_kernel<BM, BN, NW, WP>), smem);
+        YDL_SET_MAX_LDS((igemm2p_kernel<BM, BN, NW, WP, RED>), smem);
         if (per_cu < 0) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, igemm2p_kernel<BM, BN, NW, WP>, NW * 64, smem) != hipSuccess) nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, igemm2p_kernel<BM, BN, NW, WP, RED>, NW * 64, smem) != hipSuccess) nb = 0;
             per_cu = nb;
         }
         int G = ydl_device_cus() * per_cu;
@@ -1672,17 +1780,18 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
         const int ntiles = mtiles * a.grid_n;
         // measured (tools/conv_bench.py --persist 0/1, config-2 layers): +5..10 % with 128-wide tiles once a CTA walks >= 2.5 tiles,
         // neutral to -12 % below that (a second resident CTA overlaps better than a short walk) and with 64-wide tiles
-        if (persist && g_ring_persist && BN == 128 && min_taps * spt >= 2 && G >= 8 && 2 * ntiles >= 5 * G) {
+        // (not with the fused reduce: its epilogue on top of the walk's two descriptor sets spills 41 VGPRs)
+        if (persist && g_ring_persist && !RED && BN == 128 && min_taps * spt >= 2 && G >= 8 && 2 * ntiles >= 5 * G) {
             static const std::string nmp = nm + ":persistent";
             ydl_note_kernel(fam, nmp.c_str());
-            igemm2p_kernel<BM, BN, NW, WP><<<G, NW * 64, smem, st>>>(a);
+            igemm2p_kernel<BM, BN, NW, WP, RED><<<G, NW * 64, smem, st>>>(a);
             YDL_LAUNCH_CHECK();
             return 0;
         }
     }
-    YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S>), smem);
+    YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S, RED>), smem);
     ydl_note_kernel(fam, nm.c_str());
-    igemm2_kernel<BM, BN, NW, WP, S><<<grid, NW * 64, smem, st>>>(a);
+    igemm2_kernel<BM, BN, NW, WP, S, RED><<<grid, NW * 64, smem, st>>>(a);
     YDL_LAUNCH_CHECK();
     return 0;
 }
@@ -1690,7 +1799,17 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 // ring instantiations: id -> (BM, BN)
 static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128};
 static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64};
+static bool ring_has_bnred(int id) { return id == 7 || id == 9 || id == 13; }
 static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
+    if (a.br.nseg > 0) {          // epilogue with the fused BatchNorm-backward reduce: the instantiations the dgrads of the models use
+        switch (id) {
+            case 7: return launch_igemm2<128, 128, 8, 4, 2, true>(a, st, fam);
+            case 9: return launch_igemm2<64, 128, 4, 2, 3, true>(a, st, fam);
+            case 13: return launch_igemm2<128, 64, 8, 4, 2, true>(a, st, fam);
+        }
+        ydl_set_error("fused BatchNorm reduce: no instantiation for this ring configuration (query ydl_conv_dgrad_bnred_supported)");
+        return 1;
+    }
     switch (id) {
         case 1: return launch_igemm2<256, 128, 8, 4, 3>(a, st, fam);
         case 2: return launch_igemm2<128, 128, 4, 2, 4>(a, st, fam);
@@ -1748,11 +1867,14 @@ static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int 
     return c;
 }
 
+// path_out != nullptr: no launch, *path_out = the kernel family this geometry runs on (0 register-staged tiles, 1 point-wise
+// streaming kernel, 2 LDS-DMA ring, 3 stem kernel)
 template <typename T>
-static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid_m_out = nullptr, int force_bm = 0) {
+static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid_m_out = nullptr, int force_bm = 0, int* path_out = nullptr) {
     if constexpr (sizeof(T) == 2) {
         if (fam == 0 && !force_bm && args_stem(a)) {
             const StemPlan sp = stem_plan(a.M, a.Wo);
+            if (sp.ok && path_out) { *path_out = 3; return 0; }
             if (sp.ok) {
                 StemArgs q{};
                 q.X = (const bf16_t*)a.A; q.W = (const bf16_t*)a.B; q.Y = (bf16_t*)a.C; q.stats = a.stats;
@@ -1768,7 +1890,9 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
     }
     {
         const PwPlan pl = pw_plan(a.M, a.Kc, a.Cout, a.Cst, (int)sizeof(T), args_pointwise(a));
+        if (pl.ok && !force_bm && path_out) { *path_out = 1; return 0; }
         if (pl.ok && !force_bm) {
+            YDL_CHECK(a.br.nseg == 0, "fused BatchNorm reduce: this geometry runs on the point-wise kernel (query ydl_conv_dgrad_bnred_supported)");
             PwArgs q{};
             q.X = a.A; q.W = a.B; q.Y = a.C; q.stats = a.stats;
             q.M = a.M; q.lda = a.lda; q.ldc = a.ldc; q.Cout = a.Cout; q.WN = pl.WN; q.accumulate = a.accumulate;
@@ -1786,10 +1910,13 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
     TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2, a.Kc, a.Ttot);
     if constexpr (sizeof(T) == 2) {
         if (c.ring && !force_bm) {
+            if (path_out) { *path_out = ring_has_bnred(c.ring) ? 2 : 4; return 0; }
             if (grid_m_out) *grid_m_out = (a.M + c.BM - 1) / c.BM;
             return launch_ring(c.ring, a, st, fam);
         }
     }
+    if (path_out) { *path_out = 0; return 0; }
+    YDL_CHECK(a.br.nseg == 0, "fused BatchNorm reduce: this geometry runs on the register-staged kernel (query ydl_conv_dgrad_bnred_supported)");
     if (c.ring) c = pick_cfg(a.M, a.Cst);
     if (force_bm) c.BM = force_bm;
     static const int env_bm = getenv("YDL_FORCE_BM") ? atoi(getenv("YDL_FORCE_BM")) : 0;     // tuning runs only
@@ -1899,10 +2026,10 @@ extern "C" int ydl_conv_fwd_sums(const ydl_conv_geom* g, int dtype, const void* 
     return conv_fwd_impl(g, dtype, x, w, y, sums, 1, accumulate, stream);
 }
 
-extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
-                              int accumulate, void* stream) {
+static int conv_dgrad_impl(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
+                           int accumulate, const ydl_bnred* red, int* path_out, void* stream) {
     if (int e = check_geom(g, dtype)) return e;
-    YDL_CHECK(aligned16(dy) && aligned16(wt) && aligned16(dx), "pointers must be 16-byte aligned");
+    YDL_CHECK(path_out || (aligned16(dy) && aligned16(wt) && aligned16(dx)), "pointers must be 16-byte aligned");
     YDL_CHECK(g->ldy >= round_up(g->Cout, 8), "dy pixel stride must cover Cout rounded up to 8");
     hipStream_t st = (hipStream_t)stream;
     const int s = g->s, k = g->k, pd = g->p;
@@ -1944,6 +2071,7 @@ extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy,
         a.Cst = g->Cin;
         a.in_mul = 1; a.out_mul = s;
         a.Ttot = k * k; a.accumulate = accumulate;
+        if (red) a.br = *red;
         return a;
     };
     if (g_dgrad_merge && ncls > 1 && ncls <= 4 && total_taps <= MAXTAPS) {
@@ -1970,8 +2098,10 @@ extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy,
         for (int i = 0; i < ncls; ++i) a.M += a.cls_M[i];       // tile choice sees the whole launch
         (void)maxM;
         if (int e2 = set_extents(a, dtype)) return e2;
-        return dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 1) : dispatch_igemm<bf16_t>(a, st, 1);
+        return dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 1, nullptr, 0, path_out) : dispatch_igemm<bf16_t>(a, st, 1, nullptr, 0, path_out);
     }
+    if (path_out && ncls > 1) { *path_out = 0; return 0; }       // one launch per class (debug knob): no fused form
+    YDL_CHECK(red == nullptr || ncls == 1, "fused BatchNorm reduce needs the single-launch dgrad");
     for (int ci = 0; ci < ncls; ++ci) {
         const Cls& c = cls[ci];
         IgemmArgs a = base_args();
@@ -1980,10 +2110,38 @@ extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy,
         a.ntaps = c.nt;
         for (int t = 0; t < c.nt; ++t) { a.dh[t] = c.dh[t]; a.dw[t] = c.dw[t]; a.wt[t] = c.wt[t]; }
         if (int e2 = set_extents(a, dtype)) return e2;
-        int e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 1) : dispatch_igemm<bf16_t>(a, st, 1);
+        int e = dtype == YDL_F32 ? dispatch_igemm<float>(a, st, 1, nullptr, 0, path_out) : dispatch_igemm<bf16_t>(a, st, 1, nullptr, 0, path_out);
         if (e) return e;
     }
     return 0;
+}
+
+extern "C" int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
+                              int accumulate, void* stream) {
+    return conv_dgrad_impl(g, dtype, dy, wt, dx, accumulate, nullptr, nullptr, stream);
+}
+
+extern "C" int ydl_conv_dgrad_bnred_supported(const ydl_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != YDL_BF16) return 0;
+    int path = -1;
+    if (conv_dgrad_impl(g, dtype, nullptr, nullptr, nullptr, 0, nullptr, &path, nullptr) != 0) return 0;
+    return path == 2 ? 1 : 0;
+}
+
+extern "C" int ydl_conv_dgrad_bnred(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
+                                    int accumulate, const ydl_bnred* red, void* stream) {
+    YDL_CHECK(red != nullptr && (red->nseg == 1 || red->nseg == 2), "one or two channel segments");
+    YDL_CHECK(dtype == YDL_BF16, "the fused reduce exists for bf16 only");
+    for (int i = 0; i < red->nseg; ++i) {
+        YDL_CHECK(red->c0[i] >= 0 && red->c0[i] < red->c1[i] && red->c0[i] % 8 == 0 && red->c1[i] % 8 == 0 && red->c1[i] <= round_up(g->Cin, 8),
+                  "segment channel range must be 8-aligned inside the gradient's channels");
+        YDL_CHECK(red->cp[i] >= red->c1[i] - red->c0[i] && red->ldy[i] >= red->c1[i] - red->c0[i], "segment strides too small");
+        YDL_CHECK(red->y[i] && red->scale[i] && red->shift[i] && red->mean[i] && red->invstd[i] && red->sums[i], "null segment pointer");
+        YDL_CHECK(aligned16(red->y[i]) && (red->ldy[i] * 2) % 16 == 0, "segment y must be 16-byte aligned");
+        YDL_CHECK(red->act[i] == YDL_ACT_NONE || red->act[i] == YDL_ACT_SILU, "segment activation: none or SiLU");
+    }
+    YDL_CHECK(red->nseg == 1 || red->c1[0] <= red->c0[1], "segments must be ordered and disjoint");
+    return conv_dgrad_impl(g, dtype, dy, wt, dx, accumulate, red, nullptr, stream);
 }
 
 // ======================================================================================================

@@ -11,6 +11,7 @@ enum { OP_CALL = 0, OP_RECORD = 1, OP_WAIT = 2 };
 struct ReplayOp {
     int kind, fn, stream, nargs;
     ydl_conv_geom geom;
+    ydl_bnred red;
     Slot a[32];
 };
 }  // namespace
@@ -50,6 +51,12 @@ extern "C" int ydl_replay_add_call(ydl_replay* r, int fn, const int64_t* args, i
         const ydl_conv_geom* g = (const ydl_conv_geom*)(uintptr_t)args[gi];
         YDL_CHECK(g != nullptr, "null geometry");
         op.geom = *g;
+    }
+    const int ri = kReplayFnRed[fn];
+    if (ri >= 0) {
+        const ydl_bnred* b = (const ydl_bnred*)(uintptr_t)args[ri];
+        YDL_CHECK(b != nullptr, "null reduce descriptor");
+        op.red = *b;
     }
     r->ops.push_back(op);
     return 0;

@@ -86,7 +86,7 @@ class Recorder:
             raise TypeError(f"{name}: {len(args)} arguments for {len(argtypes)} parameters")
         vals = []
         for a, t in zip(args[:-1], argtypes[:-1]):
-            if t is _G:
+            if t is _G or t is L._R:
                 obj = getattr(a, "_obj", None)
                 if obj is None:
                     obj = a.contents

@@ -91,7 +91,7 @@ def zero_(t: torch.Tensor, st=None) -> torch.Tensor:
 class Var:
     """A NHWC activation: ``t`` is a logical (N,C,H,W) torch view whose memory is [N][H][W][ld] with c fastest."""
     __slots__ = ("t", "N", "C", "H", "W", "ld", "g", "gset", "need", "parent", "c0", "children", "tape", "dt", "rep", "alias",
-                 "cat_parts", "real", "ext_src")
+                 "cat_parts", "real", "ext_src", "nuse", "wcount", "bn_src", "bnred")
 
     def __init__(self, tape: "Tape", t: torch.Tensor, ld: int, need: bool, parent: Optional["Var"] = None, c0: int = 0):
         self.tape = tape
@@ -117,6 +117,13 @@ class Var:
         # every other consumer goes through Tape.materialize, which builds the real tensor once (``real``).
         self.cat_parts = None
         self.real = None
+        # fused BatchNorm-backward reduce (Tape._try_bnred): on the TOP buffer, nuse = pending consumers (a hint) and wcount = the
+        # write log (the validation), both as absolute channel ranges; on a conv+BN output, bn_src = what a consumer's dgrad epilogue
+        # needs to run this layer's reduce pass, bnred = (sums, length of the write log right after that dgrad's write) once one has
+        self.nuse = None          # top buffer: channel ranges of the recorded ops that will still write into its gradient
+        self.wcount = None        # top buffer: channel ranges written so far, in order
+        self.bn_src = None
+        self.bnred = None
         # lazily converted region input: the caller's (N,C,H,W) f32 tensor; the NHWC copy is made by Tape.materialize on
         # first use — or never, when the first layer is a stem conv that reads a space-to-depth conversion instead
         self.ext_src = None
@@ -126,6 +133,22 @@ class Var:
         while v.alias:
             v = v.parent
         return v
+
+    def top(self) -> "Var":
+        """the Var that owns the buffer (slices and alias views share their parent's gradient storage)"""
+        v = self
+        while v.parent is not None:
+            v = v.parent
+        return v
+
+    def abs_range(self) -> tuple:
+        """[c0, c1) of this Var in its top buffer's channels"""
+        c0, v = 0, self
+        while v.parent is not None:
+            if not v.alias:
+                c0 += v.c0
+            v = v.parent
+        return (c0, c0 + self.C)
 
     @property
     def npix(self) -> int:
@@ -258,11 +281,93 @@ class Tape:
             return False
         v.g = dout
         v.gset = True
+        self._note_write(v)
         return True
+
+    def _try_bnred(self, x: Var, gp, dy: Var, wt: torch.Tensor, gx: torch.Tensor, acc: int, st) -> bool:
+        """the input gradient of a convolution with the BatchNorm-backward REDUCE pass of the layer(s) that produced ``x`` in its
+        epilogue (ydl_conv_dgrad_bnred) — when this is, as far as the forward pass could tell, the last write of that gradient
+        (no pending consumer on the buffer), the producers are plain conv+BN(+SiLU) outputs covering 8-aligned channel ranges, and
+        the geometry runs on a kernel that has the fused epilogue.  The producers find (sums, write count) on their output Var and
+        skip their own reduce launch if nothing wrote the buffer in between (Tape.conv_bn_act.bw); a wrong guess only wastes the
+        epilogue work."""
+        from . import config as _cfg
+        if not _cfg.bn_bwd_fuse() or self.dt != L.YDL_BF16:
+            return False
+        xr = x.root()
+        tp = xr.top()
+        pend = tp.nuse or ()
+
+        def last_writer(v: Var) -> bool:
+            a, b = v.abs_range()
+            return not any(r[0] < b and a < r[1] for r in pend)
+        segs = []
+        if xr.bn_src is not None:
+            if last_writer(xr):
+                segs.append((0, xr))
+        else:
+            for c in xr.children:
+                if c.bn_src is not None and not c.alias and last_writer(c):
+                    segs.append((c.c0, c))
+        if not segs or len(segs) > 2:
+            return False
+        segs.sort(key=lambda e: e[0])
+        if len(segs) == 2 and segs[0][0] + segs[0][1].C > segs[1][0]:
+            return False
+        if not L.lib().ydl_conv_dgrad_bnred_supported(gp, self.dt):
+            return False
+        red = L.BnRed()
+        red.nseg = len(segs)
+        keep = []
+        for i, (c0, v) in enumerate(segs):
+            yptr, ldy, cf, co, cw, act, ykeep = v.bn_src
+            cp = round_up(cw, 8)
+            sums = self.zeroed(L.BN_REPLICAS * 2 * cp)
+            red.c0[i], red.c1[i], red.ldy[i], red.cp[i], red.act[i] = c0, c0 + cw, ldy, cp, act
+            red.y[i] = yptr
+            red.scale[i], red.shift[i] = cf["scale"][co:].data_ptr(), cf["shift"][co:].data_ptr()
+            red.mean[i], red.invstd[i] = cf["mean"][co:].data_ptr(), cf["invstd"][co:].data_ptr()
+            red.sums[i] = sums.data_ptr()
+            keep.append((v, sums))
+        L.call("ydl_conv_dgrad_bnred", gp, self.dt, _p(dy.t), _p(wt), _p(gx), acc, ctypes.byref(red), st)
+        wc = len(tp.wcount)
+        for v, sums in keep:
+            v.bnred = (sums, wc)
+        self._keep.append(red)
+        return True
+
+    def _use(self, v: Optional[Var]) -> None:
+        """forward-time note: a recorded op will later write d/dv (hint for Tape._try_bnred; a missing note only costs a fallback)"""
+        if v is not None and self.record:
+            v = v.root()
+            tp = v.top()
+            if tp.nuse is None:
+                tp.nuse = []
+            tp.nuse.append(v.abs_range())
+
+    def _unwritten_since(self, o: Var, n: int) -> bool:
+        """no gradient write has touched o's channels since the write log of its buffer had n entries"""
+        o = o.root()
+        a, b = o.abs_range()
+        log = o.top().wcount or ()
+        return not any(r[0] < b and a < r[1] for r in log[n:])
+
+    def _note_write(self, v: Var) -> None:
+        tp = v.top()
+        r = v.abs_range()
+        if tp.wcount is None:
+            tp.wcount = []
+        tp.wcount.append(r)
+        if tp.nuse:
+            try:
+                tp.nuse.remove(r)
+            except ValueError:
+                pass
 
     def grad_target(self, v: Var) -> (torch.Tensor, int):
         """(buffer, accumulate) for a kernel about to write d/dv; marks v as set."""
         v = v.root()
+        self._note_write(v)
         g = self._gbuf(v)
         acc = 1 if v.is_set() else 0
         if not acc and v.children and any(c.gset for c in v.children):
@@ -545,6 +650,17 @@ class Tape:
             raise RuntimeError("backward through eval-mode BatchNorm is not supported")
 
         train_w, train_g, train_b = m.trainable()
+        if subs is None and x.need:
+            self._use(x)
+        if res is not None and res.need and res_mode in (L.RES_BEFORE_ACT, L.RES_AFTER_ACT):
+            self._use(res)
+        if (sums_mode and _cfg.bn_bwd_fuse() and self.dt == L.YDL_BF16 and rep == 1 and act in (L.ACT_NONE, L.ACT_SILU)
+                and res_mode in (L.RES_NONE, L.RES_AFTER_ACT)):
+            # what the dgrad of this output's LAST consumer needs to run this layer's reduce pass in its epilogue
+            es2 = y.t.element_size()
+            for (co, cw, o) in parts:
+                if cw % 8 == 0 and o.aligned():
+                    o.bn_src = (y.t.data_ptr() + co * es2, y.ld, cf, co, cw, act, y)
 
         def bw():
             if not any(o.is_set() for (_c, _w, o) in parts):
@@ -577,10 +693,17 @@ class Tape:
                     if racc:
                         rmode = res_mode | L.RES_GRAD_ACCUMULATE
                 if sums_mode:
-                    L.call("ydl_bn_act_bwd_sums", self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld, _p(dout), o.ld,
+                    red = o.bnred
+                    o.bnred = None
+                    if red is not None and self._unwritten_since(o, red[1]):
+                        # the reduce pass ran in the epilogue of the dgrad that wrote dout last (nothing has written since)
+                        entry, sums_b = "ydl_bn_act_bwd_apply_sums", red[0]
+                    else:
+                        entry, sums_b = "ydl_bn_act_bwd_sums", self.zeroed(L.BN_REPLICAS * 2 * cp)
+                    L.call(entry, self.dt, _p(y.t if single else y.t[:, co:co + cw]), y.ld, _p(dout), o.ld,
                            _p(o.t), o.ld, _p(cf["mean"][co:]), _p(cf["invstd"][co:]), _p(cf["scale"][co:]), _p(cf["shift"][co:]),
                            rmode, act, _p(dyv), dy.ld, _p(dres_t), dres_ld, _p(gw[co:]), _p(gb[co:]), accw,
-                           _p(self.zeroed(L.BN_REPLICAS * 2 * cp)), npix, cw, cp, st2)
+                           _p(sums_b), npix, cw, cp, st2)
                     continue
                 nws = L.lib().ydl_bn_bwd_ws_bytes(npix, cp) // 4
                 ws2 = torch.empty(nws, dtype=torch.float32, device=self.device)
@@ -606,7 +729,8 @@ class Tape:
                 m.wgrad(self, gp, x, dy, st2)
             if x.need:
                 gx, acc = self.grad_target(x)
-                L.call("ydl_conv_dgrad", gp, self.dt, _p(dy.t), _p(wt), _p(gx), acc, st2)
+                if not self._try_bnred(x, gp, dy, wt, gx, acc, st2):
+                    L.call("ydl_conv_dgrad", gp, self.dt, _p(dy.t), _p(wt), _p(gx), acc, st2)
             _keep = (geom,)   # keep the ctypes struct alive for the closure
 
         self.bw.append(bw)
@@ -680,6 +804,7 @@ class Tape:
         L.call("ydl_maxpool_fwd", x.dt, _p(x.t), x.ld, _p(out.t), out.ld, _p(idx), x.N, x.H, x.W, Ho, Wo, x.C,
                k, s, p, _stream())
         if self.record:
+            self._use(x)
             def bw():
                 if not out.is_set() or not x.need:
                     return
@@ -709,6 +834,8 @@ class Tape:
         L.call("ydl_sppf_pool_fwd", x.dt, _p(x.t), x.ld, _p(o1.t), _p(o2.t), _p(o3.t), o1.ld, _p(idx[0]), _p(idx[1]), _p(idx[2]),
                x.N, x.H, x.W, x.C, k, _stream())
         if self.record:
+            self._use(x)
+
             def bw():
                 st = _stream()
                 if all(o.is_set() for o in outs) and x.need:
