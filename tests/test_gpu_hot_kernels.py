@@ -134,9 +134,10 @@ PW = [
     ("pw_rb256_f32", "f32", 4, 64, 128, "pw_kernel<f32,256,8,4,direct>"),
     ("pw_rb512_ct4_f32", "f32", 4, 128, 64, "pw_kernel<f32,512,4,4,direct>"),
     ("pw_rb512_nw8_f32", "f32", 4, 128, 128, "pw_kernel<f32,512,8,8,direct>"),
-    ("pw_rb128_bf16", "bf16", 4, 64, 128, "pw_kernel<bf16,128,8,4,ts>"),
-    ("pw_rb256_bf16", "bf16", 4, 128, 128, "pw_kernel<bf16,256,8,4,ts>"),
+    ("pw_rb128_bf16", "bf16", 4, 64, 128, "pw_kernel<bf16,128,4,4,ts>"),
+    ("pw_rb256_bf16", "bf16", 4, 128, 128, "pw_kernel<bf16,256,4,4,ts>"),
     ("pw_rb256_c256_bf16", "bf16", 4, 128, 256, "pw_kernel<bf16,256,8,4,ts>"),
+    ("pw_rb128_c256_bf16", "bf16", 4, 64, 256, "pw_kernel<bf16,128,8,4,ts>"),
     ("pw_rb512_bf16", "bf16", 4, 256, 64, "pw_kernel<bf16,512,4,4,ts>"),
     # 256 -> 128 @160^2: the 8-wave instantiation of the benchmark's head (8 launches per step)
     ("pw_rb512_nw8_bf16", "bf16", 4, 256, 128, "pw_kernel<bf16,512,8,8,ts>"),

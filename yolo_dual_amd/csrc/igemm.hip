@@ -1641,8 +1641,11 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
     const long wbytes = (long)Cout * RB;
     if (wbytes > 128 * 1024) return pl;
     pl.RB = RB;
-    static const int ct4 = getenv("YDL_PW_CT4") ? atoi(getenv("YDL_PW_CT4")) : 0;      // tuning: 64 channels per wave
-    pl.CT = (Cout >= 128 && !(ct4 && Cout == 128)) ? 8 : 4;
+    // 128 output channels on 128/256-byte bf16 rows: two waves of 64 channels each beat one wave of 128 (tools/conv_bench.py,
+    // 128->128 @160^2: forward 59.4 -> 53.1 us, dgrad 53.1 -> 47.7 us; 64->128: 40.3 -> 39.3 us).  YDL_PW_CT4=0: one wave, 2: also f32 / 512-byte rows
+    static const int ct4 = getenv("YDL_PW_CT4") ? atoi(getenv("YDL_PW_CT4")) : 1;
+    const bool split128 = Cout == 128 && (ct4 == 2 || (ct4 == 1 && es == 2 && RB <= 256));
+    pl.CT = (Cout >= 128 && !split128) ? 8 : 4;
     pl.WN = Cout / (pl.CT * 16);
     // 512-byte rows x 128+ channels need ~230 VGPRs: as 4-wave CTAs that is one wave per SIMD; one 8-wave CTA per CU
     // gives two
