@@ -136,11 +136,13 @@ PW = [
     ("pw_rb512_nw8_f32", "f32", 4, 128, 128, "pw_kernel<f32,512,8,8,direct>"),
     ("pw_rb128_bf16", "bf16", 4, 64, 128, "pw_kernel<bf16,128,4,4,ts>"),
     ("pw_rb256_bf16", "bf16", 4, 128, 128, "pw_kernel<bf16,256,4,4,ts>"),
-    ("pw_rb256_c256_bf16", "bf16", 4, 128, 256, "pw_kernel<bf16,256,8,4,ts>"),
-    ("pw_rb128_c256_bf16", "bf16", 4, 64, 256, "pw_kernel<bf16,128,8,4,ts>"),
+    ("pw_rb256_c256_bf16", "bf16", 4, 128, 256, "pw_kernel<bf16,256,4,4,ts>"),
+    ("pw_rb128_c256_bf16", "bf16", 4, 64, 256, "pw_kernel<bf16,128,4,4,ts>"),
     ("pw_rb512_bf16", "bf16", 4, 256, 64, "pw_kernel<bf16,512,4,4,ts>"),
-    # 256 -> 128 @160^2: the 8-wave instantiation of the benchmark's head (8 launches per step)
-    ("pw_rb512_nw8_bf16", "bf16", 4, 256, 128, "pw_kernel<bf16,512,8,8,ts>"),
+    # 256 -> 128: 512-byte rows on 64-channel waves
+    ("pw_rb512_c128_bf16", "bf16", 4, 256, 128, "pw_kernel<bf16,512,4,4,ts>"),
+    # 256 -> 256: the 8-wave instantiation (direct stores)
+    ("pw_rb512_nw8_bf16", "bf16", 4, 256, 256, "pw_kernel<bf16,512,8,8,direct>"),
 ]
 
 

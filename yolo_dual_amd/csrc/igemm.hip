@@ -1641,11 +1641,13 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
     const long wbytes = (long)Cout * RB;
     if (wbytes > 128 * 1024) return pl;
     pl.RB = RB;
-    // 128 output channels on 128/256-byte bf16 rows: two waves of 64 channels each beat one wave of 128 (tools/conv_bench.py,
-    // 128->128 @160^2: forward 59.4 -> 53.1 us, dgrad 53.1 -> 47.7 us; 64->128: 40.3 -> 39.3 us).  YDL_PW_CT4=0: one wave, 2: also f32 / 512-byte rows
+    // bf16: waves of 64 output channels instead of 128 wherever the weight matrix is at most 64 KB (tools/conv_bench.py: 128->128
+    // @160^2 forward 59.4 -> 53.1 us, dgrad 53.1 -> 47.7; 128->256 @80^2 38.5 -> 27.6; 256->128 @80^2 29.6 -> 26.7; 64->128 @160^2
+    // 40.3 -> 39.3) — but not 256->256 on 512-byte rows (42 -> 58 us: four waves would each fetch the whole activation tile).
+    // YDL_PW_CT4=0: 128-channel waves everywhere, 2: 64-channel waves for every 128-channel layer incl. f32
     static const int ct4 = getenv("YDL_PW_CT4") ? atoi(getenv("YDL_PW_CT4")) : 1;
-    const bool split128 = Cout == 128 && (ct4 == 2 || (ct4 == 1 && es == 2 && RB <= 256));
-    pl.CT = (Cout >= 128 && !split128) ? 8 : 4;
+    const bool split = (ct4 == 1 && es == 2 && (Cout == 128 || (Cout == 256 && RB <= 256))) || (ct4 == 2 && Cout == 128);
+    pl.CT = (Cout >= 128 && !split) ? 8 : 4;
     pl.WN = Cout / (pl.CT * 16);
     // 512-byte rows x 128+ channels need ~230 VGPRs: as 4-wave CTAs that is one wave per SIMD; one 8-wave CTA per CU
     // gives two
