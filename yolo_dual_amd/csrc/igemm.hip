@@ -1242,7 +1242,10 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     constexpr int ES = sizeof(T);
     constexpr int J = RB / 64;                  // fragment groups per K row (each = 4 lane-group chunks of 16 B)
     constexpr int CPR = RB / 16;                // chunks per row
-    constexpr int NB = (J >= 8) ? 3 : 4;        // pixel tiles in flight per wave (register budget)
+#ifndef PW_NB_SHORT
+#define PW_NB_SHORT 4
+#endif
+    constexpr int NB = (J >= 8) ? 3 : PW_NB_SHORT;        // pixel tiles in flight per wave (register budget)
     constexpr int NV = CT * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;                                      // [Cout][RB], chunk q of row r at slot q ^ sw(r)
@@ -1652,7 +1655,8 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
     // 512-byte rows x 128+ channels need ~230 VGPRs: as 4-wave CTAs that is one wave per SIMD; one 8-wave CTA per CU
     // gives two
     pl.NW = (RB == 512 && pl.CT == 8) ? 8 : 4;
-    const int slots = ydl_device_cus() * (pl.NW == 4 ? 2 : 1);
+    static const int slots4 = getenv("YDL_PW_SLOTS") ? atoi(getenv("YDL_PW_SLOTS")) : 2;      // CTAs per CU the 4-wave forms are sized for
+    const int slots = ydl_device_cus() * (pl.NW == 4 ? slots4 : 1);
     int bm = round_up((M + slots - 1) / slots, 16);
     pl.block_m = bm;
     pl.grid_m = (M + bm - 1) / bm;
