@@ -100,12 +100,18 @@ TILED = [
     # bf16: the throughput-mode instantiations of the same tiles (3x3 layers below 200 k pixels: the 128-wide weight-gradient kernel
     # sized to one wave of CTAs; 1x1 layers: the 64x64-tile kernel)
     # (>= 128 output channels and Cin % 64 == 0: the LDS-DMA ring kernel igemm2; otherwise igemm_kernel)
-    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
+    # 3x3 / stride 1 with the image a multiple of 8 x 16: the patch-form kernel (activation patch loaded once per channel block)
+    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2h_kernel<128,128,2>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<128>", "")),
+    # ... the same layer on a 152 x 152 image (not a multiple of 16): the ring kernel
+    ("k3_128x128_ring_bf16", "bf16", 4, 128, 128, 3, 1, 152, 152, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
-    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
+    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<64>", "")),
+    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
+    # two channel blocks through the 64-wide patch kernel, partial second channel tile in the dgrad (96 channels)
+    ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<64>", "")),
     ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "wgrad3_kernel<128>", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
-    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2_kernel<128,64,8,4,2>", "wgrad3_kernel<64>", "")),
+    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<64>", "")),
     ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
     # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
     ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3_kernel<128>", "")),
@@ -423,8 +429,12 @@ def test_dgrad_with_fused_bn_backward_reduce(case):
     assert L.lib().ydl_conv_dgrad_bnred_supported(gp, L.YDL_BF16) == 1, tag
     base = (rnd(N, Hi, Wi, Cin) * 0.5).bfloat16() if acc else torch.zeros(N, Hi, Wi, Cin, device=dev, dtype=torch.bfloat16)
     dx_ref = base.clone()
-    L.call("ydl_conv_dgrad", gp, L.YDL_BF16, P(dy), P(wt), P(dx_ref), acc, st)
-    plain = L.last_kernel(1)
+    L.debug_set(8, 0)          # the reference launch on the ring kernel too (the patch-form kernel has no fused epilogue)
+    try:
+        L.call("ydl_conv_dgrad", gp, L.YDL_BF16, P(dy), P(wt), P(dx_ref), acc, st)
+        plain = L.last_kernel(1)
+    finally:
+        L.debug_set(8, 1)
     red = L.BnRed()
     red.nseg = len(segs)
     keep = []

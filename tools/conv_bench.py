@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--ring", type=int, default=1, help="0: igemm_kernel instead of the LDS-DMA ring kernel (igemm2)")
     ap.add_argument("--wg3", type=int, default=1, help="0: register-staged wgrad2 instead of the LDS-DMA wgrad3")
     ap.add_argument("--persist", type=int, default=1, help="0: one tile per CTA instead of the persistent ring kernel (igemm2p)")
+    ap.add_argument("--halo", type=int, default=1, help="0: ring kernel instead of the patch-form kernel on the 3x3 / stride-1 layers")
     ap.add_argument("--det", action="store_true", help="wgrad: deterministic slab + fixed-order reduce instead of f32 atomics")
     ap.add_argument("--check", action="store_true", help="compare fwd/dgrad of the ring kernel with igemm_kernel (max abs diff)")
     a = ap.parse_args()
@@ -43,6 +44,7 @@ def main():
     L.debug_set(3, a.ring)
     L.debug_set(4, a.wg3)
     L.debug_set(6, a.persist)
+    L.debug_set(8, a.halo)
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")

@@ -11,6 +11,7 @@
 // bf16: v_mfma_f32_16x16x32_bf16, lane reads 8 consecutive k.  f32: 4 x v_mfma_f32_16x16x4_f32 on the 4
 // floats of the same 16-byte read (k permuted identically for both operands; exact f32 fmaf chains).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #ifndef YDL_PF
@@ -1214,6 +1215,292 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void igemm2p_kernel(const IgemmArg
 }
 
 // ------------------------------------------------------------------------------------------------------
+// igemm2h: the 3x3 / stride 1 / pad 1 convolution (forward, or the equally shaped dgrad) in PATCH form.  A CTA owns an 8 x 16 block
+// of output pixels of one image; per 64-channel block it loads the (8+2) x (16+2) activation patch ONCE (LDS-DMA, rows swizzled by
+// their patch row index) and serves all nine taps from it — the ring kernel fetches the 128 activation rows again for every tap
+// (9x the L2 -> LDS activation traffic).  Weights still stream: one [BN][64] tile per (channel block, tap) through a two-stage ring,
+// so the traffic of a 128 x 128 tile per channel block is 23 KB + 9 x 16 KB instead of 9 x 32 KB.
+//   * patch rows: pixel (pr, pc) of the patch at LDS row pr * 18 + pc (184 rows allocated: 23 wave-instructions of 8 rows); pixels
+//     outside the image are out-of-range DMA offsets (zeros = the padding); two patch buffers, the next channel block's patch is
+//     requested at the first tap of the current one;
+//   * a wave's 16-pixel MFMA row tile is one image row of the block, so its fragment rows for tap (dh, dw) are the 16 CONSECUTIVE
+//     patch rows (tr + 1 + dh) * 18 + (1 + dw) + 0..15: the (row >> 1) & 7 chunk swizzle is conflict-free at any row offset;
+//   * epilogue = igemm2_epilogue with the block described as a one-image "class" (Wg = 16, Hg = 8, origin = the block's corner).
+// Requires Ho % 8 == 0 and Wo % 16 == 0 (every tile full: the BN-partial contract of 128-pixel blocks holds unchanged).
+// ------------------------------------------------------------------------------------------------------
+#define H_PW 18
+#define H_PROWS 192      // 10 x 18 = 180 patch rows, rounded to whole DMA passes of the 8-wave CTA (3 x 64)
+// outstanding DMAs (per thread) that may remain when step g's weights are needed: the S - 2 younger weight steps plus the patch
+// passes issued by the S - 1 loop iterations before this one (one pass at each of the taps 0..2)
+template <int S, int BR, int PP>
+__host__ __device__ constexpr int halo_wait(int tap) {
+    int n = (S - 2) * BR;
+    for (int d = 1; d <= S - 1; ++d) n += ((tap - d + 9 * 8) % 9) < PP ? 1 : 0;
+    return n;
+}
+template <int BN, int NW, int WP, int S>
+__global__ __launch_bounds__(NW * 64) void igemm2h_kernel(const IgemmArgs p) {
+    using T = bf16_t;
+    constexpr int ES = 2;
+    constexpr int BM = 128;
+    constexpr int RPP = NW * 8;                              // LDS rows one DMA pass of the CTA covers
+    constexpr int BR = BN / RPP;                             // weight DMAs per thread per step
+    constexpr int PP = (H_PROWS + RPP - 1) / RPP;            // patch DMA passes per channel block, one per step at taps 0 .. PP-1
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    constexpr int PBYTES = H_PROWS * GROWB;
+    constexpr int RBYTES = BN * GROWB;
+    static_assert(BN % RPP == 0 && PP <= 3 && S >= 2 && S <= 7, "stage geometry");
+    static_assert(2 * PBYTES + S * RBYTES >= BM * BN * 2 + 8192, "epilogue scratch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem + 2 * PBYTES;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WN, wp = wave / WN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mtile, ntile;
+    if (p.m_fastest) { ntile = tile / p.grid_m; mtile = tile - ntile * p.grid_m; }
+    else { mtile = tile / p.grid_n; ntile = tile - mtile * p.grid_n; }
+    const int tiles_w = p.Wo >> 4, tiles_hw = (p.Ho >> 3) * tiles_w;
+    const int n = mtile / tiles_hw;
+    const int rem = mtile - n * tiles_hw;
+    const int h0 = (rem / tiles_w) << 3, w0 = (rem % tiles_w) << 4;
+    const int n0 = ntile * BN;
+
+    // this thread's DMA slots: row r of each pass, 16-byte slot qs; it fetches the logical chunk qs ^ swizzle(row in its buffer)
+    const int r = t >> 3, qs = t & 7;
+    unsigned poff[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int rho = r + RPP * i;
+        const int pr = rho / H_PW, pc = rho - pr * H_PW;
+        const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+        const bool ok = rho < 10 * H_PW && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
+        poff[i] = ok ? (unsigned)(((n * p.Hi + h) * p.Wi + w) * p.lda) * (unsigned)ES + (unsigned)((qs ^ ((rho >> 1) & 7)) << 4) : 0xFFFFFFFFu;
+    }
+    unsigned browoff[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int row = r + RPP * i;
+        const int co = n0 + row;
+        browoff[i] = co < p.Cout ? (unsigned)co * p.ldb_bytes + (unsigned)((qs ^ ((row >> 1) & 7)) << 4) : 0xF0000000u;
+    }
+    const int spt = p.Kc >> 6;
+    const int nsteps = 9 * spt;
+    u32x4 rsA, rsB;
+    {
+        const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+        rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
+        rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xffffu, p.bytesB, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_lds = lds0 + (unsigned)wave * (8 * GROWB);
+    // pass i of the patch of channel block cb -> patch buffer cb & 1.  EVERY thread issues exactly one DMA per call (the vmcnt
+    // arithmetic is uniform); a block beyond the last sends out-of-range offsets into the buffer the last block does not use
+    auto issue_patch = [&](int cb, int i) {
+        const bool live = cb < spt && poff[i] != 0xFFFFFFFFu;
+        const unsigned base = wave_lds + (unsigned)(cb & 1) * PBYTES + (unsigned)(i * RPP * GROWB);
+        lds_dma16(rsA, base, live ? poff[i] + ((unsigned)cb << 7) : 0xFFFFFFFFu);
+    };
+    auto issue_w = [&](int g, int stg) {                     // weight tile of step g = (channel block g / 9, tap g % 9)
+        const int cb = g / 9, tap = g - cb * 9;
+        const bool live = g < nsteps;
+        const unsigned add = live ? (unsigned)p.wt[tap] * (unsigned)p.Kc * ES + ((unsigned)cb << 7) : 0xF0000000u;
+        const unsigned base = wave_lds + 2u * PBYTES + (unsigned)stg * RBYTES;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) lds_dma16(rsB, base + i * RPP * GROWB, browoff[i] + add);
+    };
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int sw_w = (lrow >> 1) & 7;
+    const unsigned char* const fa = ring + (wc * BNW + lrow) * GROWB;           // weights (MFMA A operand)
+    // prologue: the first patch, then S - 1 weight steps
+#pragma unroll
+    for (int i = 0; i < PP; ++i) issue_patch(0, i);
+#pragma unroll
+    for (int u = 0; u < S - 1; ++u) issue_w(u, u);
+    int stg = 0;
+    // one step; the tap is a compile-time constant (the vmcnt immediate depends on it), FIRST = channel block 0
+    auto step = [&](auto tapc, auto firstc, int cb) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr bool first = decltype(firstc)::value;
+        const int g = cb * 9 + tap;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // outstanding DMAs younger than step g's weights: S - 2 weight steps + the patch passes of the iterations since its issue
+        constexpr int npp = first ? (tap < S - 1 ? (tap < PP ? tap : PP) : halo_wait<S, BR, PP>(tap) - (S - 2) * BR)
+                                  : halo_wait<S, BR, PP>(tap) - (S - 2) * BR;
+        wait_vm_barrier<(S - 2) * BR + npp>();
+        {
+            int nst = stg + S - 1;
+            if (nst >= S) nst -= S;
+            issue_w(g + S - 1, nst);                         // into the stage step g - 1 occupied
+        }
+        if constexpr (tap < PP) issue_patch(cb + 1, tap);    // the next channel block's patch, one pass per step
+        const int dh = (int)p.dh[tap], dw = (int)p.dw[tap];
+        const unsigned char* const wst = fa + stg * RBYTES;
+        const unsigned char* const pst = smem + (cb & 1) * PBYTES;
+        int prow[PT];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) prow[j] = (wp * PT + j + 1 + dh) * H_PW + (lrow + 1 + dw);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 af[CT], bfr[PT];
+            const int kq = lgrp + 4 * half;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(wst + c * 16 * GROWB + ((kq ^ sw_w) << 4));
+#pragma unroll
+            for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(pst + prow[j] * GROWB + ((kq ^ ((prow[j] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+        }
+        stg = stg + 1 == S ? 0 : stg + 1;
+    };
+#define H_STEPS(F, CB)                                                                                                          \
+    step(std::integral_constant<int, 0>{}, F, CB); step(std::integral_constant<int, 1>{}, F, CB);                              \
+    step(std::integral_constant<int, 2>{}, F, CB); step(std::integral_constant<int, 3>{}, F, CB);                              \
+    step(std::integral_constant<int, 4>{}, F, CB); step(std::integral_constant<int, 5>{}, F, CB);                              \
+    step(std::integral_constant<int, 6>{}, F, CB); step(std::integral_constant<int, 7>{}, F, CB);                              \
+    step(std::integral_constant<int, 8>{}, F, CB)
+    H_STEPS(std::true_type{}, 0);
+    for (int cb = 1; cb < spt; ++cb) { H_STEPS(std::false_type{}, cb); }
+#undef H_STEPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vm_barrier<0>();                                    // the trailing all-zero DMAs have landed; the LDS is free
+    igemm2_epilogue<BM, BN, NW, WP>(p, acc, smem, 0, n0, mtile, BM, 16, 8, n * p.Ho + h0, w0);
+}
+
+// The same kernel with a TWO-stage weight ring, 184-row patches and a rolled step loop: 79 VGPRs and 78 KB of LDS, so that two CTAs
+// share a CU — for 128-wide tiles that matters more than ring depth (one CTA per CU with 3 / 4 / 6 weight stages in flight:
+// 128->128 k3 @80^2 forward 62 / 61 / 66 us against 51 us here and 53 us for the ring kernel).
+#define HS_PROWS 184
+template <int BN, int NW, int WP>
+__global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
+    using T = bf16_t;
+    constexpr int ES = 2;
+    constexpr int BM = 128;
+    constexpr int RPP = NW * 8;
+    constexpr int BR = BN / RPP;
+    constexpr int PP = (HS_PROWS + RPP - 1) / RPP;
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    constexpr int PBYTES = HS_PROWS * GROWB;
+    constexpr int RBYTES = BN * GROWB;
+    static_assert(BN % RPP == 0 && 2 * PBYTES >= BM * BN * 2 + 8192, "stage geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem + 2 * PBYTES;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WN, wp = wave / WN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mtile, ntile;
+    if (p.m_fastest) { ntile = tile / p.grid_m; mtile = tile - ntile * p.grid_m; }
+    else { mtile = tile / p.grid_n; ntile = tile - mtile * p.grid_n; }
+    const int tiles_w = p.Wo >> 4, tiles_hw = (p.Ho >> 3) * tiles_w;
+    const int n = mtile / tiles_hw;
+    const int rem = mtile - n * tiles_hw;
+    const int h0 = (rem / tiles_w) << 3, w0 = (rem % tiles_w) << 4;
+    const int n0 = ntile * BN;
+    const int r = t >> 3, qs = t & 7;
+    unsigned poff[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int rho = r + RPP * i;
+        const int pr = rho / H_PW, pc = rho - pr * H_PW;
+        const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+        const bool ok = rho < 10 * H_PW && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
+        poff[i] = ok ? (unsigned)(((n * p.Hi + h) * p.Wi + w) * p.lda) * (unsigned)ES + (unsigned)((qs ^ ((rho >> 1) & 7)) << 4) : 0xFFFFFFFFu;
+    }
+    unsigned browoff[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int row = r + RPP * i;
+        const int co = n0 + row;
+        browoff[i] = co < p.Cout ? (unsigned)co * p.ldb_bytes + (unsigned)((qs ^ ((row >> 1) & 7)) << 4) : 0xF0000000u;
+    }
+    const int spt = p.Kc >> 6;
+    const int nsteps = 9 * spt;
+    u32x4 rsA, rsB;
+    {
+        const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+        rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
+        rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xffffu, p.bytesB, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_lds = lds0 + (unsigned)wave * (8 * GROWB);
+    auto issue_patch = [&](int cb) {
+        const unsigned base = wave_lds + (unsigned)(cb & 1) * PBYTES;
+        const unsigned kb = (unsigned)cb << 7;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+            if (RPP * i + wave * 8 < HS_PROWS)               // (wave-uniform) rows beyond the allocation are not written
+                lds_dma16(rsA, base + i * RPP * GROWB, poff[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : poff[i] + kb);
+        }
+    };
+    auto issue_w = [&](int g) {
+        const int cb = g / 9, tap = g - cb * 9;
+        const bool live = g < nsteps;
+        const unsigned add = live ? (unsigned)p.wt[tap] * (unsigned)p.Kc * ES + ((unsigned)cb << 7) : 0xF0000000u;
+        const unsigned base = wave_lds + 2u * PBYTES + (unsigned)(g & 1) * RBYTES;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) lds_dma16(rsB, base + i * RPP * GROWB, browoff[i] + add);
+    };
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int sw_w = (lrow >> 1) & 7;
+    const unsigned char* const fa = ring + (wc * BNW + lrow) * GROWB;
+    issue_patch(0);
+    issue_w(0);
+    for (int g = 0; g < nsteps; ++g) {
+        const int cb = g / 9, tap = g - cb * 9;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vm_barrier<0>();                                // step g's weights (and its patch) landed; everyone is done with step g - 1
+        issue_w(g + 1);
+        if (tap == 0 && cb + 1 < spt) issue_patch(cb + 1);
+        const int dh = (int)p.dh[tap], dw = (int)p.dw[tap];
+        const unsigned char* const wst = fa + (g & 1) * RBYTES;
+        const unsigned char* const pst = smem + (cb & 1) * PBYTES;
+        int prow[PT];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) prow[j] = (wp * PT + j + 1 + dh) * H_PW + (lrow + 1 + dw);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 af[CT], bfr[PT];
+            const int kq = lgrp + 4 * half;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(wst + c * 16 * GROWB + ((kq ^ sw_w) << 4));
+#pragma unroll
+            for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(pst + prow[j] * GROWB + ((kq ^ ((prow[j] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vm_barrier<0>();
+    igemm2_epilogue<BM, BN, NW, WP>(p, acc, smem, 0, n0, mtile, BM, 16, 8, n * p.Ho + h0, w0);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Point-wise (1x1, stride 1) convolutions with a short K (row = 128..512 bytes of K) on large pixel counts.
 // These layers are HBM-bound (2 bytes in + 2 bytes out per MAC row) and the tiled kernel above runs them at ~45 % of
 // the HBM rate: with 2..4 K-steps a CTA is three dependent memory round trips (load, load, store) and two CTAs per CU
@@ -1808,6 +2095,49 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 // ring instantiations: id -> (BM, BN)
 static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128};
 static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64};
+// patch-form 3x3 / stride-1 kernel (igemm2h_kernel): eligibility and launch
+static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
+static bool halo_ok(const IgemmArgs& a, int id) {
+    static const int env = getenv("YDL_HALO") ? atoi(getenv("YDL_HALO")) : 1;
+    if (!env || !g_halo || (id != 7 && id != 13) || a.br.nseg > 0) return false;
+    if (a.ncls > 1 || a.ntaps != 9 || a.Ttot != 9 || a.in_mul != 1 || a.out_mul != 1 || a.out_h0 != 0 || a.out_w0 != 0) return false;
+    if (a.Hi != a.Ho || a.Wi != a.Wo || a.Hg != a.Ho || a.Wg != a.Wo || (a.Ho & 7) || (a.Wo & 15) || (a.Kc & 63)) return false;
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int t = 0; t < 9; ++t) {
+        const int dh = a.dh[t], dw = a.dw[t];
+        if (dh < -1 || dh > 1 || dw < -1 || dw > 1 || seen[(dh + 1) * 3 + dw + 1]) return false;
+        seen[(dh + 1) * 3 + dw + 1] = true;
+    }
+    return true;
+}
+template <int BN, int S>
+static int launch_igemm2h(IgemmArgs a, hipStream_t st, int fam) {
+    constexpr int NW = 8, WP = 4;
+    a.grid_n = (a.Cst + BN - 1) / BN;
+    a.grid_m = a.M / 128;                                  // every tile is full (halo_ok)
+    YDL_CHECK(a.bytesB < 0x08000000u, "ring kernel: weight matrix of 128 MiB or more is not supported");
+    {
+        static const int forced = getenv("YDL_RING_MFAST") ? atoi(getenv("YDL_RING_MFAST")) : -1;
+        const double wbytes = (double)a.Cout * a.Ttot * a.Kc * 2.0;
+        const double abytes = (double)a.N * a.Hi * a.Wi * a.lda * 2.0;
+        a.m_fastest = (wbytes > 2.0e6 && (double)a.grid_m * wbytes > (double)a.grid_n * abytes) ? 1 : 0;
+        if (forced >= 0) a.m_fastest = forced;
+    }
+    static const std::string nm = std::string("igemm2h_kernel<128,") + std::to_string(BN) + "," + std::to_string(S) + ">";
+    ydl_note_kernel(fam, nm.c_str());
+    if constexpr (S == 2) {
+        const size_t smem = 2 * (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB;
+        YDL_SET_MAX_LDS((igemm2hs_kernel<BN, NW, WP>), smem);
+        igemm2hs_kernel<BN, NW, WP><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
+    } else {
+        const size_t smem = 2 * (size_t)H_PROWS * GROWB + (size_t)S * BN * GROWB;
+        YDL_SET_MAX_LDS((igemm2h_kernel<BN, NW, WP, S>), smem);
+        igemm2h_kernel<BN, NW, WP, S><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
+    }
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool ring_has_bnred(int id) { return id == 7 || id == 9 || id == 13; }
 static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
     if (a.br.nseg > 0) {          // epilogue with the fused BatchNorm-backward reduce: the instantiations the dgrads of the models use
@@ -1818,6 +2148,19 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         }
         ydl_set_error("fused BatchNorm reduce: no instantiation for this ring configuration (query ydl_conv_dgrad_bnred_supported)");
         return 1;
+    }
+    if (halo_ok(a, id)) {
+        // weight ring depth: 6 stages x 16 KB + two patches = 144 KB, one CTA per CU with five weight steps in flight; 64-wide tiles
+        // 3 stages x 8 KB = 72 KB, two CTAs per CU (YDL_HALO_S: tuning)
+        static const int hs = getenv("YDL_HALO_S") ? atoi(getenv("YDL_HALO_S")) : 0;
+        if (id == 7) {
+            if (hs == 3) return launch_igemm2h<128, 3>(a, st, fam);
+            if (hs == 6) return launch_igemm2h<128, 6>(a, st, fam);
+            return launch_igemm2h<128, 2>(a, st, fam);
+        }
+        if (hs == 6) return launch_igemm2h<64, 6>(a, st, fam);
+        if (hs == 2) return launch_igemm2h<64, 2>(a, st, fam);
+        return launch_igemm2h<64, 3>(a, st, fam);
     }
     switch (id) {
         case 1: return launch_igemm2<256, 128, 8, 4, 3>(a, st, fam);
@@ -2809,6 +3152,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 2 = strided dgrad: 1 (default) all output-parity classes in one launch, 0 one launch per class
 //              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
 //              key 3 = bf16 LDS-DMA ring kernel (igemm2) for the MFMA-bound layers: 1 (default) on, 0 off (igemm_kernel everywhere)
+//              key 8 = patch-form kernel for the 3x3 / stride-1 layers (igemm2h_kernel): 1 (default) on, 0 ring kernel
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
 //              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
@@ -2822,6 +3166,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 4) g_wgrad_dma = val;
     if (key == 5) g_stem_enabled = val;
     if (key == 6) g_ring_persist = val;
+    if (key == 8) g_halo = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
