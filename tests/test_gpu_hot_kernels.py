@@ -107,11 +107,11 @@ TILED = [
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
     ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<64>", "")),
     ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
-    # two channel blocks through the 64-wide patch kernel, partial second channel tile in the dgrad (96 channels)
-    ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<64>", "")),
+    # one channel block: the single-patch-buffer form (four CTAs per CU)
+    ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
     ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "wgrad3_kernel<128>", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
-    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<64>", "")),
+    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
     ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
     # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
     ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3_kernel<128>", "")),

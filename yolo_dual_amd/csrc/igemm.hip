@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2h_kernel(const IgemmArgs p) {
     constexpr int PT = BM / (16 * WP);
     constexpr int PBYTES = H_PROWS * GROWB;
     constexpr int RBYTES = BN * GROWB;
-    static_assert(BN % RPP == 0 && PP <= 3 && S >= 2 && S <= 7, "stage geometry");
+    static_assert(BN % RPP == 0 && PP <= 9 && S >= 2 && S <= 7 && PP + S <= 10, "stage geometry (the last patch pass must be older than the step that needs it)");
     static_assert(2 * PBYTES + S * RBYTES >= BM * BN * 2 + 8192, "epilogue scratch");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem + 2 * PBYTES;
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2h_kernel(const IgemmArgs p) {
 // share a CU — for 128-wide tiles that matters more than ring depth (one CTA per CU with 3 / 4 / 6 weight stages in flight:
 // 128->128 k3 @80^2 forward 62 / 61 / 66 us against 51 us here and 53 us for the ring kernel).
 #define HS_PROWS 184
-template <int BN, int NW, int WP>
+template <int BN, int NW, int WP, bool ONEP = false>      // ONEP: one channel block (Cin = 64) needs one patch buffer: 40 KB, four CTAs per CU
 __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
     using T = bf16_t;
     constexpr int ES = 2;
@@ -1399,9 +1399,10 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
     constexpr int PT = BM / (16 * WP);
     constexpr int PBYTES = HS_PROWS * GROWB;
     constexpr int RBYTES = BN * GROWB;
-    static_assert(BN % RPP == 0 && 2 * PBYTES >= BM * BN * 2 + 8192, "stage geometry");
+    static_assert(BN % RPP == 0 && (ONEP ? 1 : 2) * PBYTES + 2 * RBYTES >= BM * BN * 2 + 8192, "stage geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const ring = smem + 2 * PBYTES;
+    constexpr int NPB = ONEP ? 1 : 2;
+    unsigned char* const ring = smem + NPB * PBYTES;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1443,7 +1444,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned wave_lds = lds0 + (unsigned)wave * (8 * GROWB);
     auto issue_patch = [&](int cb) {
-        const unsigned base = wave_lds + (unsigned)(cb & 1) * PBYTES;
+        const unsigned base = wave_lds + (unsigned)(ONEP ? 0 : (cb & 1)) * PBYTES;
         const unsigned kb = (unsigned)cb << 7;
 #pragma unroll
         for (int i = 0; i < PP; ++i) {
@@ -1455,7 +1456,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
         const int cb = g / 9, tap = g - cb * 9;
         const bool live = g < nsteps;
         const unsigned add = live ? (unsigned)p.wt[tap] * (unsigned)p.Kc * ES + ((unsigned)cb << 7) : 0xF0000000u;
-        const unsigned base = wave_lds + 2u * PBYTES + (unsigned)(g & 1) * RBYTES;
+        const unsigned base = wave_lds + (unsigned)NPB * PBYTES + (unsigned)(g & 1) * RBYTES;
 #pragma unroll
         for (int i = 0; i < BR; ++i) lds_dma16(rsB, base + i * RPP * GROWB, browoff[i] + add);
     };
@@ -1474,10 +1475,19 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vm_barrier<0>();                                // step g's weights (and its patch) landed; everyone is done with step g - 1
         issue_w(g + 1);
-        if (tap == 0 && cb + 1 < spt) issue_patch(cb + 1);
+        if constexpr (ONEP) {
+            // one patch buffer: the next channel block's patch can only be requested once every wave has left the old one (the
+            // barrier above), and is waited for at once — the other resident CTAs (four per CU at 40 KB) cover the round trip
+            if (tap == 0 && cb > 0) {
+                issue_patch(cb);
+                wait_vm_barrier<0>();
+            }
+        } else {
+            if (tap == 0 && cb + 1 < spt) issue_patch(cb + 1);
+        }
         const int dh = (int)p.dh[tap], dw = (int)p.dw[tap];
         const unsigned char* const wst = fa + (g & 1) * RBYTES;
-        const unsigned char* const pst = smem + (cb & 1) * PBYTES;
+        const unsigned char* const pst = smem + (ONEP ? 0 : (cb & 1)) * PBYTES;
         int prow[PT];
 #pragma unroll
         for (int j = 0; j < PT; ++j) prow[j] = (wp * PT + j + 1 + dh) * H_PW + (lrow + 1 + dw);
@@ -2110,9 +2120,9 @@ static bool halo_ok(const IgemmArgs& a, int id) {
     }
     return true;
 }
-template <int BN, int S>
+template <int BN, int S, int NW = 8>
 static int launch_igemm2h(IgemmArgs a, hipStream_t st, int fam) {
-    constexpr int NW = 8, WP = 4;
+    constexpr int WP = 4;
     a.grid_n = (a.Cst + BN - 1) / BN;
     a.grid_m = a.M / 128;                                  // every tile is full (halo_ok)
     YDL_CHECK(a.bytesB < 0x08000000u, "ring kernel: weight matrix of 128 MiB or more is not supported");
@@ -2123,12 +2133,19 @@ static int launch_igemm2h(IgemmArgs a, hipStream_t st, int fam) {
         a.m_fastest = (wbytes > 2.0e6 && (double)a.grid_m * wbytes > (double)a.grid_n * abytes) ? 1 : 0;
         if (forced >= 0) a.m_fastest = forced;
     }
-    static const std::string nm = std::string("igemm2h_kernel<128,") + std::to_string(BN) + "," + std::to_string(S) + ">";
+    static const std::string nm = std::string("igemm2h_kernel<128,") + std::to_string(BN) + "," + std::to_string(S) + (NW == 8 ? ">" : ",nw4>");
     ydl_note_kernel(fam, nm.c_str());
     if constexpr (S == 2) {
-        const size_t smem = 2 * (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB;
-        YDL_SET_MAX_LDS((igemm2hs_kernel<BN, NW, WP>), smem);
-        igemm2hs_kernel<BN, NW, WP><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
+        static const int onep_all = getenv("YDL_HALO_ONEP") ? atoi(getenv("YDL_HALO_ONEP")) : 0;     // 1: one patch buffer for any channel count
+        if (a.Kc == 64 || (onep_all && BN == 64)) {
+            const size_t smem = (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB;
+            YDL_SET_MAX_LDS((igemm2hs_kernel<BN, NW, WP, true>), smem);
+            igemm2hs_kernel<BN, NW, WP, true><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
+        } else {
+            const size_t smem = 2 * (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB;
+            YDL_SET_MAX_LDS((igemm2hs_kernel<BN, NW, WP>), smem);
+            igemm2hs_kernel<BN, NW, WP><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
+        }
     } else {
         const size_t smem = 2 * (size_t)H_PROWS * GROWB + (size_t)S * BN * GROWB;
         YDL_SET_MAX_LDS((igemm2h_kernel<BN, NW, WP, S>), smem);
@@ -2159,7 +2176,10 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
             return launch_igemm2h<128, 2>(a, st, fam);
         }
         if (hs == 6) return launch_igemm2h<64, 6>(a, st, fam);
-        if (hs == 2) return launch_igemm2h<64, 2>(a, st, fam);
+        if (hs == 43) return launch_igemm2h<64, 3, 4>(a, st, fam);       // four waves of 32 x 64: 16 MFMAs per wave and barrier (slower)
+        // one channel block: the two-stage form with ONE patch buffer is 40 KB — four CTAs per CU (64->64 k3 @160^2: forward
+        // 66.8 -> 58.5 us, dgrad 54.2 -> 51.2); more channel blocks: three weight stages, two patches, two CTAs per CU
+        if (hs == 2 || (hs == 0 && a.Kc == 64)) return launch_igemm2h<64, 2>(a, st, fam);
         return launch_igemm2h<64, 3>(a, st, fam);
     }
     switch (id) {
