@@ -1403,7 +1403,17 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NPB = ONEP ? 1 : 2;
     unsigned char* const ring = smem + NPB * PBYTES;
+    // per-tap tables in LDS (patch-row delta of the tap, byte offset of its weight slice).  A run-time index into the byte arrays of
+    // the kernel ARGUMENTS compiles to `global_load_sbyte` (there are no sub-dword scalar loads) and an `s_waitcnt vmcnt(0)` in front
+    // of its first use — which drained the weight DMA issued just before it, in every step (tools/asm_loops.py flags such loads)
+    int* const sTd = (int*)(ring + 2 * RBYTES);
+    int* const sTw = sTd + 16;
     const int t = threadIdx.x;
+    if (t < 9) {
+        sTd[t] = (int)p.dh[t] * H_PW + (int)p.dw[t];
+        sTw[t] = (int)p.wt[t] * p.Kc * ES;
+    }
+    __syncthreads();
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wc = wave % WN, wp = wave / WN;
@@ -1452,11 +1462,9 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
                 lds_dma16(rsA, base + i * RPP * GROWB, poff[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : poff[i] + kb);
         }
     };
-    auto issue_w = [&](int g) {
-        const int cb = g / 9, tap = g - cb * 9;
-        const bool live = g < nsteps;
-        const unsigned add = live ? (unsigned)p.wt[tap] * (unsigned)p.Kc * ES + ((unsigned)cb << 7) : 0xF0000000u;
-        const unsigned base = wave_lds + (unsigned)NPB * PBYTES + (unsigned)(g & 1) * RBYTES;
+    auto issue_w = [&](int stg, int cbw, int woff) {          // weight tile of a step: channel block cbw, tap slice at byte offset woff
+        const unsigned add = cbw < spt ? (unsigned)woff + ((unsigned)cbw << 7) : 0xF0000000u;
+        const unsigned base = wave_lds + (unsigned)NPB * PBYTES + (unsigned)stg * RBYTES;
 #pragma unroll
         for (int i = 0; i < BR; ++i) lds_dma16(rsB, base + i * RPP * GROWB, browoff[i] + add);
     };
@@ -1469,12 +1477,18 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
     const int sw_w = (lrow >> 1) & 7;
     const unsigned char* const fa = ring + (wc * BNW + lrow) * GROWB;
     issue_patch(0);
-    issue_w(0);
+    issue_w(0, 0, sTw[0]);
+    // (cb, tap) of step g and the table entries it needs, read one step ahead: dcur = patch-row delta of step g, wnx = weight offset of
+    // step g + 1
+    int cb = 0, tap = 0;
+    int dcur = sTd[0], wnx = sTw[1];
     for (int g = 0; g < nsteps; ++g) {
-        const int cb = g / 9, tap = g - cb * 9;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vm_barrier<0>();                                // step g's weights (and its patch) landed; everyone is done with step g - 1
-        issue_w(g + 1);
+        const int t1 = tap == 8 ? 0 : tap + 1, c1 = tap == 8 ? cb + 1 : cb;      // step g + 1
+        const int t2 = t1 == 8 ? 0 : t1 + 1;                                      // tap of step g + 2
+        const int dnx = sTd[t1], wnn = sTw[t2];              // used by the next iteration
+        issue_w((g + 1) & 1, c1, wnx);
         if constexpr (ONEP) {
             // one patch buffer: the next channel block's patch can only be requested once every wave has left the old one (the
             // barrier above), and is waited for at once — the other resident CTAs (four per CU at 40 KB) cover the round trip
@@ -1485,12 +1499,11 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
         } else {
             if (tap == 0 && cb + 1 < spt) issue_patch(cb + 1);
         }
-        const int dh = (int)p.dh[tap], dw = (int)p.dw[tap];
         const unsigned char* const wst = fa + (g & 1) * RBYTES;
         const unsigned char* const pst = smem + (ONEP ? 0 : (cb & 1)) * PBYTES;
         int prow[PT];
 #pragma unroll
-        for (int j = 0; j < PT; ++j) prow[j] = (wp * PT + j + 1 + dh) * H_PW + (lrow + 1 + dw);
+        for (int j = 0; j < PT; ++j) prow[j] = (wp * PT + j + 1) * H_PW + (lrow + 1) + dcur;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint4 af[CT], bfr[PT];
@@ -1504,6 +1517,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
         }
+        dcur = dnx; wnx = wnn; tap = t1; cb = c1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wait_vm_barrier<0>();
@@ -2138,11 +2152,11 @@ static int launch_igemm2h(IgemmArgs a, hipStream_t st, int fam) {
     if constexpr (S == 2) {
         static const int onep_all = getenv("YDL_HALO_ONEP") ? atoi(getenv("YDL_HALO_ONEP")) : 0;     // 1: one patch buffer for any channel count
         if (a.Kc == 64 || (onep_all && BN == 64)) {
-            const size_t smem = (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB;
+            const size_t smem = (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB + 128;
             YDL_SET_MAX_LDS((igemm2hs_kernel<BN, NW, WP, true>), smem);
             igemm2hs_kernel<BN, NW, WP, true><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
         } else {
-            const size_t smem = 2 * (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB;
+            const size_t smem = 2 * (size_t)HS_PROWS * GROWB + 2 * (size_t)BN * GROWB + 128;
             YDL_SET_MAX_LDS((igemm2hs_kernel<BN, NW, WP>), smem);
             igemm2hs_kernel<BN, NW, WP><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
         }
