@@ -109,7 +109,11 @@ TILED = [
     ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
     # one channel block: the single-patch-buffer form (four CTAs per CU)
     ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
-    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "wgrad3_kernel<128>", "")),
+    # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
+    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
+    ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
+    # ... a dy grid of 88 x 88 (not a multiple of 16): the ring kernel, one launch over the four classes
+    ("k3s2_64_128_ring_bf16", "bf16", 8, 64, 128, 3, 2, 176, 176, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
     ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
     ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
@@ -219,6 +223,38 @@ def test_bf16_dgrad_accumulate_variants_against_oracle():
     for k, p in ps.items():
         e = l2_err(named[k].grad.detach().float().cpu(), p.grad)
         assert e < 6e-2, (k, e)
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+@pytest.mark.parametrize("cin,cout,N,Ho,Wo", [(64, 128, 2, 24, 32), (192, 64, 1, 16, 48), (72, 128, 2, 8, 16)])
+def test_fused_stride2_dgrad_through_the_c_abi(cin, cout, N, Ho, Wo, accumulate):
+    """ydl_conv_dgrad of a 3x3 / stride 2 / pad 1 convolution on the fused-parity kernel (igemm2s_kernel), overwrite and accumulate, against
+    torch's conv2d input gradient in float64 on the same bf16 operands (seg_diceloss_yolov5.py:388-409 backward): image-border blocks,
+    several channel blocks of dy, a partial last cin tile (192 = 3 x 64, 72 = 64 + 8) and the read-modify-write epilogue"""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    rs = np.random.RandomState(cin + cout + accumulate)
+    Hi, Wi = 2 * Ho, 2 * Wo
+    dy = torch.from_numpy(rs.standard_normal((N, cout, Ho, Wo)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cout)).astype(np.float32)).bfloat16()
+    dx0 = torch.from_numpy(rs.standard_normal((N, cin, Hi, Wi)).astype(np.float32)).bfloat16()
+    ref = torch.nn.grad.conv2d_input((N, cin, Hi, Wi), w.double(), dy.double(), stride=2, padding=1)
+    if accumulate:
+        ref = ref + dx0.double()
+    dev = torch.device("cuda")
+    dy_g = dy.permute(0, 2, 3, 1).contiguous().to(dev)                       # NHWC
+    wt_g = w.permute(1, 2, 3, 0).reshape(cin, 9, cout).contiguous().to(dev)   # [Cin][tap][Cout]
+    dx_g = dx0.permute(0, 2, 3, 1).contiguous().to(dev)
+    g = L.ConvGeom(N, Hi, Wi, cin, Ho, Wo, cout, 3, 2, 1, cin, cout)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.call("ydl_conv_dgrad", ctypes.byref(g), L.YDL_BF16, P(dy_g), P(wt_g), P(dx_g), accumulate, st)
+    torch.cuda.synchronize()
+    assert L.last_kernel(1) == ("igemm2s_kernel<128,64,2,acc>" if accumulate else "igemm2s_kernel<128,64,3>"), L.last_kernel(1)
+    got = dx_g.float().permute(0, 3, 1, 2).cpu().double()
+    # one bf16 rounding of an f32 accumulation: 2^-9 relative per element; judged in relative L2 and as a max error against the largest value
+    assert l2_err(got, ref) < 4e-3, l2_err(got, ref)
+    assert float((got - ref).abs().max()) < 1.6e-2 * float(ref.abs().max())
 
 
 def test_bn_finalize_two_level_merge_against_oracle():
@@ -429,12 +465,14 @@ def test_dgrad_with_fused_bn_backward_reduce(case):
     assert L.lib().ydl_conv_dgrad_bnred_supported(gp, L.YDL_BF16) == 1, tag
     base = (rnd(N, Hi, Wi, Cin) * 0.5).bfloat16() if acc else torch.zeros(N, Hi, Wi, Cin, device=dev, dtype=torch.bfloat16)
     dx_ref = base.clone()
-    L.debug_set(8, 0)          # the reference launch on the ring kernel too (the patch-form kernel has no fused epilogue)
+    L.debug_set(8, 0)          # the reference launch on the ring kernel too (the patch-form kernels have no fused epilogue)
+    L.debug_set(9, 0)
     try:
         L.call("ydl_conv_dgrad", gp, L.YDL_BF16, P(dy), P(wt), P(dx_ref), acc, st)
         plain = L.last_kernel(1)
     finally:
         L.debug_set(8, 1)
+        L.debug_set(9, 1)
     red = L.BnRed()
     red.nseg = len(segs)
     keep = []

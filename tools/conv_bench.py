@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--wg3", type=int, default=1, help="0: register-staged wgrad2 instead of the LDS-DMA wgrad3")
     ap.add_argument("--persist", type=int, default=1, help="0: one tile per CTA instead of the persistent ring kernel (igemm2p)")
     ap.add_argument("--halo", type=int, default=1, help="0: ring kernel instead of the patch-form kernel on the 3x3 / stride-1 layers")
+    ap.add_argument("--s2", type=int, default=1, help="0: ring kernel instead of the fused-parity kernel on the k3 s2 p1 data gradients")
     ap.add_argument("--det", action="store_true", help="wgrad: deterministic slab + fixed-order reduce instead of f32 atomics")
     ap.add_argument("--check", action="store_true", help="compare fwd/dgrad of the ring kernel with igemm_kernel (max abs diff)")
     a = ap.parse_args()
@@ -45,6 +46,7 @@ def main():
     L.debug_set(4, a.wg3)
     L.debug_set(6, a.persist)
     L.debug_set(8, a.halo)
+    L.debug_set(9, a.s2)
     dt = L.YDL_BF16 if a.dtype == "bf16" else L.YDL_F32
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")

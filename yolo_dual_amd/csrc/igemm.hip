@@ -40,6 +40,7 @@ struct IgemmArgs {
     int stats_atomic; // 0: stats = per-block partial rows [gridM][2][stats_ld] (sum, M2);  1: stats = [YDL_BN_REPLICAS][2][stats_ld]
                       //    running (sum, sum of squares), every block adds its share with f32 atomics (replica = block index & 7)
     unsigned bytesA, bytesB;   // buffer extents for the range-checked loads
+    unsigned bytesC;           // extent of C (igemm2s_kernel's accumulate pre-pass reads it by LDS-DMA; 0 = not set)
     unsigned ldb_bytes;        // byte stride between weight rows (Ttot*Kc*ES when dense)
     // several output-parity classes in one launch (stride-s dgrad); ncls <= 1: the single-class fields above apply
     int ncls;
@@ -495,7 +496,7 @@ __device__ __forceinline__ void br_fill_coef(const IgemmArgs& p, float* scoef, i
 template <int BM, int BN, int NW, int WP, bool RED = false>
 __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)[(BN / (NW / WP)) / 16][BM / (16 * WP)],
                                                 unsigned char* smem, int m0, int n0, int mtile, int c_M, int c_Wg, int c_Hg,
-                                                int c_h0, int c_w0, const float* scoef = nullptr) {
+                                                int c_h0, int c_w0, const float* scoef = nullptr, const bool acc_done = false) {
     using T = bf16_t;
     constexpr int WN = NW / WP;
     constexpr int BNW = BN / WN;
@@ -519,7 +520,7 @@ __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)
         return ((size_t)(n * p.Ho + gh * p.out_mul + c_h0)) * p.Wo + (gw * p.out_mul + c_w0);
     };
     const bool dense = p.out_mul == 1 && c_h0 == 0 && c_w0 == 0 && c_Wg == p.Wo && c_Hg == p.Ho;
-    if (p.accumulate) {          // fold the previous contents of C into the accumulators (register layout, 8-byte loads)
+    if (p.accumulate && !acc_done) {          // fold the previous contents of C into the accumulators (register layout, 8-byte loads)
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int m = m0 + wp * (BM / WP) + j * 16 + lrow;
@@ -1525,6 +1526,198 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// igemm2s: the data gradient of a 3x3 / stride 2 / pad 1 convolution with all four output-parity classes FUSED in one CTA.
+// The ring kernel runs such a dgrad as four dense sub-convolutions (1, 2, 2 and 4 taps): tiles with 2..8 K-steps whose fixed cost
+// (descriptors, first DMA round trip, epilogue) is as large as their main loop, and every class fetches the same dy rows again.
+// Here a CTA owns an 8 x 16 block of dy grid points (i, j) of one image and a 64-channel slice of dx, i.e. the 16 x 32 block of dx
+// pixels (2i + ph, 2j + pw).  With p = 1:   dx[2i]   += dy[i] w[1]         dx[2i+1] += dy[i+1] w[0] + dy[i] w[2]   (same along w)
+// so tap (kh, kw) reads dy at (i + [kh == 0], j + [kw == 0]) and feeds parity class (kh != 1, kw != 1): nine taps, one (8+1) x (16+1)
+// dy patch per 64-channel block of dy (loaded once by LDS-DMA, out-of-image pixels are out-of-range offsets = zeros), four
+// accumulator sets.  The taps are walked in groups that read the SAME dy pixels ((0,0): four taps, (0,1) and (1,0): two each,
+// (1,1): one), so the pixel fragments are read from LDS once per group: 52 fragment reads per 72 MFMAs instead of 72.
+// Weights stream as in igemm2hs_kernel: one [64 cin][64] tile per (channel block, tap) through a two-stage ring.
+// Epilogue: igemm2_epilogue once per class (the block described as a one-image class with out_mul = 2 and the class's origin).
+// Requires k = 3, s = 2, p = 1, Hdx = 2 Hdy, Wdx = 2 Wdy, Hdy % 8 == 0, Wdy % 16 == 0, Cout % 64 == 0 (the K dimension).
+// ------------------------------------------------------------------------------------------------------
+#define S2_PW 17
+#define S2_PROWS 192      // 9 x 17 = 153 patch rows, rounded to whole DMA passes of the 8-wave CTA (3 x 64): every thread issues the same number of DMAs
+__device__ constexpr int kS2Kh[9] = {1, 1, 2, 2, 1, 2, 0, 0, 0};       // tap order: groups (dh,dw) = (0,0) x4, (0,1) x2, (1,0) x2, (1,1)
+__device__ constexpr int kS2Kw[9] = {1, 2, 1, 2, 0, 0, 1, 2, 0};
+template <int NW, int WP, int S, bool ACC>      // ACC: dx += (its own instantiation: the pre-pass below costs the plain kernel registers it does not have)
+__global__ __launch_bounds__(NW * 64, NW / 2) void igemm2s_kernel(const IgemmArgs p) {
+    using T = bf16_t;
+    constexpr int ES = 2;
+    constexpr int BM = 128, BN = 64;
+    constexpr int RPP = NW * 8;
+    constexpr int BR = BN / RPP;
+    constexpr int PP = (S2_PROWS + RPP - 1) / RPP;
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    constexpr int PBYTES = S2_PROWS * GROWB;
+    constexpr int RBYTES = BN * GROWB;
+    static_assert(BN % RPP == 0 && BR == 1 && S2_PROWS % RPP == 0 && (S == 2 || S == 3), "one weight DMA per thread and step, whole patch passes");
+    static_assert(2 * PBYTES + S * RBYTES >= BM * BN * 2, "epilogue scratch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem + 2 * PBYTES;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WN, wp = wave / WN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = tile / p.grid_n, ntile = tile - mtile * p.grid_n;
+    const int tiles_w = p.Wi >> 4, tiles_hw = (p.Hi >> 3) * tiles_w;        // (Hi, Wi) = the dy grid
+    const int n = mtile / tiles_hw;
+    const int rem = mtile - n * tiles_hw;
+    const int i0 = (rem / tiles_w) << 3, j0 = (rem % tiles_w) << 4;
+    const int n0 = ntile * BN;
+    const int r = t >> 3, qs = t & 7;
+    const unsigned browoff = (n0 + r) < p.Cout ? (unsigned)(n0 + r) * p.ldb_bytes + (unsigned)((qs ^ ((r >> 1) & 7)) << 4) : 0xF0000000u;
+    const int spt = p.Kc >> 6;
+    u32x4 rsA, rsB;
+    {
+        const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+        rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
+        rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xffffu, p.bytesB, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_lds = lds0 + (unsigned)wave * (8 * GROWB);
+    // the patch of channel block cb -> buffer cb & 1; a block beyond the last sends out-of-range offsets (zeros) into the buffer the
+    // last block does not use, so that every thread issues the same DMAs in every block (the counted waits below rely on it)
+    auto issue_patch = [&](int cb) {
+        const unsigned base = wave_lds + (unsigned)(cb & 1) * PBYTES;
+        const unsigned kb = (unsigned)cb << 7;
+        const bool live = cb < spt;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+            // (the source offsets are recomputed per block rather than kept: three registers this kernel does not have)
+            const int rho = r + RPP * i;
+            const int pr = rho / S2_PW, pc = rho - pr * S2_PW;
+            const int h = i0 + pr, w = j0 + pc;
+            const bool ok = live && rho < 9 * S2_PW && h < p.Hi && w < p.Wi;
+            const unsigned off = (unsigned)(((n * p.Hi + h) * p.Wi + w) * p.lda) * (unsigned)ES + (unsigned)((qs ^ ((rho >> 1) & 7)) << 4) + kb;
+            lds_dma16(rsA, base + i * RPP * GROWB, ok ? off : 0xFFFFFFFFu);
+        }
+    };
+    // weight tile of (channel block cb, tap slice kh*3+kw) -> ring stage stg; a block beyond the last sends out-of-range offsets (zeros)
+    auto issue_w = [&](int stg, int cb, int slice) {
+        const unsigned add = cb < spt ? (unsigned)slice * (unsigned)p.Kc * ES + ((unsigned)cb << 7) : 0xF0000000u;
+        lds_dma16(rsB, wave_lds + 2u * PBYTES + (unsigned)stg * RBYTES, browoff + add);
+    };
+    f32x4 acc[4][CT][PT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc[q][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int sw_w = (lrow >> 1) & 7;
+    const unsigned char* const fa = ring + (wc * BNW + lrow) * GROWB;
+    uint4 bq[2][PT];                                           // pixel fragments of the current tap group (both K halves)
+    // one step: tap I of the walk (compile-time: its class selects the accumulator set), channel block cb
+    auto step = [&](auto ic, int cb) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int kh = kS2Kh[I], kw = kS2Kw[I];
+        constexpr int dh = kh == 0 ? 1 : 0, dw = kw == 0 ? 1 : 0;
+        constexpr int cls = (kh != 1 ? 2 : 0) + (kw != 1 ? 1 : 0);
+        constexpr bool group_start = I == 0 || I == 4 || I == 6 || I == 8;
+        // Issue order: step h issues W(h + S - 1) and then, at tap 0, the PP patch passes of the next block.  DMAs younger than step g's
+        // weights when step g waits for them (S = 3): W(g + 1), plus the patch passes of steps g - 2 and g - 1 if those were tap 0
+        constexpr int I1 = (I + 8) % 9, I2 = (I + 7) % 9;                      // taps of steps g - 1, g - 2
+        constexpr int NY = S == 2 ? 0 : 1 + (I1 == 0 ? PP : 0) + (I2 == 0 ? PP : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vm_barrier<NY>();                                 // step g's weights (and patch) landed; everyone is done with step g - 1
+        {
+            constexpr int J = (I + S - 1) % 9;                 // step g + S - 1 = (block cbj, tap J) -> the stage step g - 1 occupied
+            const int cbj = cb + (I + S - 1) / 9;
+            issue_w(S == 3 ? J % 3 : (cbj + J) & 1, cbj, kS2Kh[J] * 3 + kS2Kw[J]);       // stage of a step: (9 cb + tap) % S
+        }
+        if constexpr (I == 0) issue_patch(cb + 1);
+        const unsigned char* const wst = fa + (S == 3 ? I % 3 : (cb + I) & 1) * RBYTES;
+        const unsigned char* const pst = smem + (cb & 1) * PBYTES;
+        if constexpr (group_start) {
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int prow = (wp * PT + j + dh) * S2_PW + (lrow + dw);
+                const unsigned char* const rowp = pst + prow * GROWB;
+                const int sw = (prow >> 1) & 7;
+                bq[0][j] = *(const uint4*)(rowp + ((lgrp ^ sw) << 4));
+                bq[1][j] = *(const uint4*)(rowp + (((lgrp + 4) ^ sw) << 4));
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 aq[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) aq[c] = *(const uint4*)(wst + c * 16 * GROWB + (((lgrp + 4 * half) ^ sw_w) << 4));
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) Mma<T>::run(aq[c], bq[half][j], acc[cls][c][j]);
+        }
+    };
+    issue_patch(0);
+    issue_w(0, 0, kS2Kh[0] * 3 + kS2Kw[0]);
+    if constexpr (S == 3) issue_w(1, 0, kS2Kh[1] * 3 + kS2Kw[1]);
+    for (int cb = 0; cb < spt; ++cb) {
+        step(std::integral_constant<int, 0>{}, cb); step(std::integral_constant<int, 1>{}, cb); step(std::integral_constant<int, 2>{}, cb);
+        step(std::integral_constant<int, 3>{}, cb); step(std::integral_constant<int, 4>{}, cb); step(std::integral_constant<int, 5>{}, cb);
+        step(std::integral_constant<int, 6>{}, cb); step(std::integral_constant<int, 7>{}, cb); step(std::integral_constant<int, 8>{}, cb);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vm_barrier<0>();                                      // the trailing all-zero DMA has landed; the LDS is free
+    if constexpr (ACC) {
+        // dx += ...: the four class tiles of the previous dx come in by LDS-DMA as whole 128-byte rows (the register-layout pre-pass of
+        // igemm2_epilogue reads 8 bytes per lane from 16 different rows per instruction — on the every-other-pixel rows of a parity
+        // class that cost 60 us on the 64->128 layer), in the swizzled image the epilogue's transpose uses; then every lane adds
+        // its 4-channel pieces (same arithmetic and rounding as the register pre-pass)
+        constexpr int CPR = BN / 8, RPS = NW * 64 / CPR, ORB = BN * 2;
+        static_assert(4 * BM * ORB <= 2 * PBYTES + S * RBYTES && CPR == 8, "the four previous tiles must fit the LDS");
+        u32x4 rsC;
+        {
+            const unsigned long long pc = (unsigned long long)p.C;
+            rsC = u32x4{(unsigned)pc, (unsigned)(pc >> 32) & 0xffffu, p.bytesC, 0x00020000u};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < BM / RPS; ++i) {
+                const int row = r + i * RPS;                   // (r = t >> 3: the row of this thread's 16-byte slot, qs its slot)
+                const int gh = row >> 4, gw = row & 15;
+                const unsigned pix = (unsigned)((n * p.Ho + 2 * (i0 + gh) + (q >> 1)) * p.Wo + 2 * (j0 + gw) + (q & 1));
+                const int co = n0 + ((qs ^ (row & 7)) << 3);
+                lds_dma16(rsC, wave_lds + (unsigned)(q * BM * ORB + i * RPS * ORB), co < p.Cst ? (pix * (unsigned)p.ldc + (unsigned)co) * ES : 0xFFFFFFFFu);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        wait_vm_barrier<0>();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int row = wp * (BM / WP) + j * 16 + lrow;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const int ch = wc * BNW + c * 16 + lgrp * 4;
+                    const uint2 q2 = *(const uint2*)(smem + q * BM * ORB + row * ORB + ((((ch >> 3) ^ (row & 7))) << 4) + ((ch & 4) << 1));
+                    acc[q][c][j] += f32x4{__uint_as_float(q2.x << 16), __uint_as_float(q2.x & 0xffff0000u),
+                                          __uint_as_float(q2.y << 16), __uint_as_float(q2.y & 0xffff0000u)};
+                }
+                __builtin_amdgcn_sched_barrier(0);             // (all sixteen reads hoisted in front of the adds spill 50 registers)
+            }
+        __syncthreads();                                       // every lane has its pieces before the epilogues reuse the LDS
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q) __syncthreads();                                // the previous class's store pass has read the scratch
+        igemm2_epilogue<BM, BN, NW, WP>(p, acc[q], smem, 0, n0, mtile, BM, 16, 8, n * p.Ho + 2 * i0 + (q >> 1), 2 * j0 + (q & 1), nullptr,
+                                        true);                 // (ACC: the previous contents are in the accumulators already; otherwise the
+                                                               //  launcher guarantees accumulate == 0: no register-layout pre-pass either way)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Point-wise (1x1, stride 1) convolutions with a short K (row = 128..512 bytes of K) on large pixel counts.
 // These layers are HBM-bound (2 bytes in + 2 bytes out per MAC row) and the tiled kernel above runs them at ~45 % of
 // the HBM rate: with 2..4 K-steps a CTA is three dependent memory round trips (load, load, store) and two CTAs per CU
@@ -2169,6 +2362,36 @@ static int launch_igemm2h(IgemmArgs a, hipStream_t st, int fam) {
     return 0;
 }
 
+// fused-parity stride-2 dgrad (igemm2s_kernel): eligibility and launch.  ``a`` is the dgrad's base argument block (A = dy, C = dx).
+static int g_s2fused = 1;       // ydl_debug_set key 9 (YDL_S2FUSED=0 at start-up)
+static bool s2fused_ok(const ydl_conv_geom* g, int dtype) {
+    static const int env = getenv("YDL_S2FUSED") ? atoi(getenv("YDL_S2FUSED")) : 1;
+    if (!env || !g_s2fused || !g_ring_enabled || dtype != YDL_BF16) return false;
+    if (g->k != 3 || g->s != 2 || g->p != 1 || g->Hi != 2 * g->Ho || g->Wi != 2 * g->Wo) return false;
+    if ((g->Ho & 7) || (g->Wo & 15) || (round_up(g->Cout, 8) & 63) || (g->Cin & 7) || g->Cin < 64) return false;
+    return true;
+}
+template <int S, bool ACC>
+static int launch_igemm2s_cfg(const IgemmArgs& a, hipStream_t st, int fam) {
+    constexpr int NW = 8, WP = 4;
+    const size_t smem = 2 * (size_t)S2_PROWS * GROWB + (size_t)S * 64 * GROWB;
+    YDL_SET_MAX_LDS((igemm2s_kernel<NW, WP, S, ACC>), smem);
+    static const std::string nm = std::string("igemm2s_kernel<128,64,") + std::to_string(S) + (ACC ? ",acc>" : ">");
+    ydl_note_kernel(fam, nm.c_str());
+    igemm2s_kernel<NW, WP, S, ACC><<<dim3(a.grid_m * a.grid_n), NW * 64, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+static int launch_igemm2s(IgemmArgs a, hipStream_t st, int fam) {
+    a.grid_n = (a.Cst + 63) / 64;
+    a.grid_m = a.N * (a.Hi >> 3) * (a.Wi >> 4);
+    YDL_CHECK(a.bytesB < 0x08000000u, "ring kernel: weight matrix of 128 MiB or more is not supported");
+    static const int stages = getenv("YDL_S2_STAGES") ? atoi(getenv("YDL_S2_STAGES")) : 3;       // tuning
+    // (accumulate: the two-stage form — the three-stage one spills inside its block loop: 64->128 @160^2 143 against 153 us)
+    if (a.accumulate) return stages == 33 ? launch_igemm2s_cfg<3, true>(a, st, fam) : launch_igemm2s_cfg<2, true>(a, st, fam);
+    return stages == 2 ? launch_igemm2s_cfg<2, false>(a, st, fam) : launch_igemm2s_cfg<3, false>(a, st, fam);
+}
+
 static bool ring_has_bnred(int id) { return id == 7 || id == 9 || id == 13; }
 static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
     if (a.br.nseg > 0) {          // epilogue with the fused BatchNorm-backward reduce: the instantiations the dgrads of the models use
@@ -2460,6 +2683,17 @@ static int conv_dgrad_impl(const ydl_conv_geom* g, int dtype, const void* dy, co
         if (red) a.br = *red;
         return a;
     };
+    if (red == nullptr && path_out == nullptr && ncls == 4 && s2fused_ok(g, dtype)) {
+        // k3 s2 p1: all four parity classes in one CTA (igemm2s_kernel)
+        IgemmArgs a = base_args();
+        a.M = g->N * g->Ho * g->Wo; a.Hg = g->Ho; a.Wg = g->Wo; a.ntaps = 9;
+        if (int e2 = set_extents(a, dtype)) return e2;
+        const unsigned long long bc = (unsigned long long)g->N * g->Hi * g->Wi * g->ldx * 2ull;
+        if (bc < 0xFFFFFFF0ull) {                            // (a larger dx is not addressable by the accumulate pre-pass: ring kernel)
+            a.bytesC = (unsigned)bc;
+            return launch_igemm2s(a, st, 1);
+        }
+    }
     if (g_dgrad_merge && ncls > 1 && ncls <= 4 && total_taps <= MAXTAPS) {
         // heavier classes first (their CTAs run longest)
         int order[4] = {0, 1, 2, 3};
@@ -3187,6 +3421,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 1 = streaming point-wise kernel for short-K 1x1 convolutions: 1 (default) on, 0 off (tiled kernel everywhere)
 //              key 3 = bf16 LDS-DMA ring kernel (igemm2) for the MFMA-bound layers: 1 (default) on, 0 off (igemm_kernel everywhere)
 //              key 8 = patch-form kernel for the 3x3 / stride-1 layers (igemm2h_kernel): 1 (default) on, 0 ring kernel
+//              key 9 = fused-parity kernel for the k3 s2 p1 data gradients (igemm2s_kernel): 1 (default) on, 0 ring kernel
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
 //              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
@@ -3201,6 +3436,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 5) g_stem_enabled = val;
     if (key == 6) g_ring_persist = val;
     if (key == 8) g_halo = val;
+    if (key == 9) g_s2fused = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
