@@ -151,6 +151,71 @@ def test_bf16_wire_all_reduce():
     _run(2, algo="allreduce", wire="bf16")
 
 
+def _overlap_worker(rank, world, port, q, wire):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yolo_dual_amd import config
+        from yolo_dual_amd.optim import FlatSGDEMA
+        from yolo_dual_amd.parallel import DataParallel
+        net = _build()
+        opt = FlatSGDEMA(net, lr=0.1)
+        dp = DataParallel(net, opt, bucket_bytes=4096, algo="rs_ag", wire=wire)
+        gen = torch.Generator().manual_seed(100 + rank)
+        results = {}
+        for overlap in (True, False):
+            dp.reducer.overlap_phase2 = overlap
+            gen.manual_seed(100 + rank)
+            outs = []
+            for step in range(3):
+                opt.zero_grad()
+                dp.begin()
+                seen2 = 0
+                for p, off, n, _g in reversed(opt._slots):
+                    opt.grads_arena[off:off + n] = torch.randn(n, generator=gen)
+                    config.mark_touched(p)
+                    seen2 = max(seen2, len(dp.reducer._phase2))
+                if step >= 1:          # the plan exists from the first finish() on: buckets go out from the hooks
+                    nb = len(dp.reducer._plan)
+                    assert nb >= 3
+                    if overlap:        # all-gathers of all buckets but the last were posted DURING backward
+                        assert seen2 == nb - 1 and len(dp.reducer._phase1) == 1, (seen2, nb)
+                    else:
+                        assert seen2 == 0 and len(dp.reducer._phase1) == nb
+                dp.finish()
+                outs.append(opt.grads_arena.clone())
+            results[overlap] = outs
+        for a, b in zip(results[True], results[False]):
+            assert torch.equal(a, b), "overlapped all-gather changed the reduced gradients"
+        allg = [torch.zeros_like(opt.grads_arena) for _ in range(world)]
+        dist.all_gather(allg, results[True][-1])
+        assert all(torch.equal(allg[0], t) for t in allg[1:])
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire", ["f32", "bf16"])
+def test_overlapped_all_gather_equals_the_serial_form(wire):
+    """rs_ag posts the all-gather of bucket k when bucket k + 1 is launched (during backward), in the same order on every rank; the
+    reduced gradients equal, bit for bit, those of the serial form that runs both phases of every bucket after backward (world 4)"""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q, wire)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def test_flat_arena_layout_and_state_dict_roundtrip():
     """parameters become views of one arena; state_dict keys/shapes are untouched and load_state_dict writes through"""
     from yolo_dual_amd.optim import FlatSGDEMA

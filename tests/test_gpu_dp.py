@@ -133,27 +133,44 @@ def test_two_rank_data_parallel_launch_list(algo, wire):
     assert all(r[1] == "ok" for r in res), res
 
 
+_CLI_ARGS = ["--batch-size", "2", "--imgsz", "64", "--steps-per-epoch", "5", "--epochs", "2", "--dtype", "f32"]
+
+
 def _cli_worker(rank, world, port, save_dir, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       LOCAL_WORLD_SIZE=str(world))
     try:
         import train_seg
-        fit = train_seg.train(train_seg.parse_opt(["--batch-size", "2", "--imgsz", "64", "--steps-per-epoch", "5", "--epochs", "2",
-                                                   "--save-dir", save_dir, "--dist-backend", "gloo", "--one-gpu", "--dtype", "f32"]))
+        fit = train_seg.train(train_seg.parse_opt(_CLI_ARGS + ["--save-dir", save_dir, "--dist-backend", "gloo", "--one-gpu"]))
         import yolo_dual_amd as ydl
         ok = 0.0 <= fit <= 1.0
         if rank == 0:
             ck = ydl.load_checkpoint(os.path.join(save_dir, "last.pt"))
             ok = ok and ck["epoch"] == 1 and ck["optimizer"] is not None
-        q.put((rank, "ok" if ok else "fail"))
+        q.put((rank, "ok" if ok else "fail", dict(train_seg.LAST_RUN)))
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put((rank, "fail: " + repr(e) + traceback.format_exc()))
+        q.put((rank, "fail: " + repr(e) + traceback.format_exc(), {}))
+
+
+def _emu_worker(save_dir, q):
+    """one process playing both ranks in turn (train_seg.py --emulate-world 2): same micro-batches, gradients summed, 1/2 in the step"""
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        os.environ.pop(k, None)
+    try:
+        import train_seg
+        train_seg.train(train_seg.parse_opt(_CLI_ARGS + ["--save-dir", save_dir, "--emulate-world", "2"]))
+        q.put((0, "ok", dict(train_seg.LAST_RUN)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((0, "fail: " + repr(e) + traceback.format_exc(), {}))
 
 
 def test_train_cli_runs_data_parallel(tmp_path):
-    """train_seg.py under two ranks (what torch.distributed.run sets up): gradient accumulation (bs 2 -> accumulate 32, one exchange
-    per optimizer step), rank 0 validates and saves"""
+    """train_seg.py under two ranks (what torch.distributed.run sets up): the nominal-batch scaling uses the TOTAL batch as the
+    reference does (seg_diceloss_yolov5.py:970-972, :1001: 2 ranks x bs 2 -> accumulate 16, weight decay x 4 x 16 / 64), one exchange
+    per optimizer step, rank 0 validates and saves; the ranks end with identical parameters, and those equal — to f32 rounding — the
+    parameters of ONE process that plays both ranks' micro-batches in turn (sum of the gradients, 1/2 in the step)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -164,3 +181,18 @@ def test_train_cli_runs_data_parallel(tmp_path):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+    facts = {r[0]: r[2] for r in res}
+    for f in facts.values():
+        assert f["world"] == 2 and f["total_batch"] == 4 and f["accumulate"] == 16, f
+        assert abs(f["weight_decay"] - 0.0005 * 4 * 16 / 64) < 1e-12, f
+    assert facts[0]["param_sum"] == facts[1]["param_sum"] and facts[0]["param_abs_sum"] == facts[1]["param_abs_sum"], facts
+    pe = ctx.Process(target=_emu_worker, args=(str(tmp_path / "emu"), q))
+    pe.start()
+    re_ = q.get(timeout=280)
+    pe.join(timeout=60)
+    assert re_[1] == "ok", re_
+    emu = re_[2]
+    assert emu["total_batch"] == 4 and emu["accumulate"] == 16, emu
+    # same products, different summation order (ranks' sums meet in the all-reduce instead of one arena): f32 rounding over two epochs
+    assert abs(emu["param_abs_sum"] - facts[0]["param_abs_sum"]) < 1e-5 * facts[0]["param_abs_sum"], (emu, facts[0])
+    assert abs(emu["param_sum"] - facts[0]["param_sum"]) < 1e-5 * facts[0]["param_abs_sum"], (emu, facts[0])

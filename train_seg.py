@@ -9,7 +9,9 @@ confusion-matrix mIoU of val_diceloss.py:37-75 on held-out synthetic batches.
 
 Multi-GPU: where the reference wraps the model in nn.DataParallel (:988-992; its SyncBN branch is dead code), this entry runs one
 process per GPU under torch.distributed.run and averages gradients with yolo_dual_amd.parallel.DataParallel (RCCL all-reduce of the
-flat gradient arena, bucketed, launched from the backward hooks).  ``--batch-size`` is per GPU; BatchNorm statistics stay per
+flat gradient arena, bucketed, launched from the backward hooks).  ``--batch-size`` is per GPU, the nominal-batch scaling of the
+reference (accumulate = round(64 / total batch), weight decay x total batch x accumulate / 64, seg_diceloss_yolov5.py:970-972) uses the
+total over all ranks, as the reference does with its batch_size before splitting it (:1001); BatchNorm statistics stay per
 replica and rank 0's are the ones validated and saved, as with nn.DataParallel, whose replica 0 owns the buffers.
 
     python train_seg.py --cfg yolo_dual_amd/cfg/yolov5_seg.yaml --weights '' --epochs 2 --batch-size 16 --imgsz 640
@@ -31,6 +33,9 @@ DEFAULT_CW = [1, 2, 25, 2, 10, 3, 25, 10, 5, 15, 25, 1]            # unet-lite/y
 ARCH = {"yolov5": ("YOLOv5Seg", "yolov5_seg.yaml", "dice"), "yolov8": ("YOLOv8Seg", "yolov8_seg.yaml", "jaccard"),
         "yolov9": ("YOLOv9Seg", "yolov9_seg.yaml", "dice"), "resnet18": ("ResNet18Seg", None, "dice"),
         "resnet50": ("ResNet50Seg", None, "dice")}
+
+
+LAST_RUN: dict = {}      # facts of the last train() call of this process (tests): world, total batch, accumulate, weight decay, parameter sums
 
 
 def parse_opt(argv=None):
@@ -65,6 +70,8 @@ def parse_opt(argv=None):
     p.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"])
     p.add_argument("--dp-wire", default="f32", choices=["f32", "bf16"])
     p.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo)")
+    p.add_argument("--emulate-world", type=int, default=0, help="debugging aid (single process): play N data-parallel ranks in turn — rank "
+                   "r's batches, gradients summed over the ranks and averaged in the step; parameters then equal an N-rank run's to rounding")
     return p.parse_args(argv)
 
 
@@ -161,9 +168,13 @@ def train(opt) -> float:
         v.requires_grad = not any(x in k for x in freeze)
 
     bs, epochs = opt.batch_size, opt.epochs
+    emu = max(int(opt.emulate_world), 0) if world == 1 else 0           # debugging aid: one process plays the ranks of a DP run in turn
+    tb = bs * (emu or world)                                            # the reference's batch_size is the TOTAL over the replicas (:1001)
     nbs = 64
-    accumulate = max(round(nbs / bs), 1)                               # :970-972
-    wd = opt.weight_decay * bs * accumulate / nbs
+    accumulate = max(round(nbs / tb), 1)                               # :970-972, on the total batch
+    wd = opt.weight_decay * tb * accumulate / nbs
+    LAST_RUN.clear()
+    LAST_RUN.update(world=world, total_batch=tb, accumulate=accumulate, weight_decay=wd)
     optimizer = ydl.smart_optimizer(model, opt.optimizer, opt.lr0, opt.momentum, wd, ema=main)       # EMA is fused into the step
     dp = None
     if world > 1:                                                                        # :988-992, as processes instead of threads
@@ -182,6 +193,7 @@ def train(opt) -> float:
     cw = class_weights(opt.class_weights, nc).to(device)
     criterion = (ydl.SegmentationLoss if loss_kind == "dice" else ydl.JaccardSegmentationLoss)(nc, opt.label_smoothing, cw)
     gen = torch.Generator(device=device).manual_seed(1000 + opt.seed + 7919 * rank)     # every rank draws its own batches
+    emu_gens = [torch.Generator(device=device).manual_seed(1000 + opt.seed + 7919 * r) for r in range(emu)]
     palette = torch.rand(nc, 3, device=device, generator=torch.Generator(device=device).manual_seed(7))
     val_gen = torch.Generator(device=device).manual_seed(99)
     lb, raw = None, None
@@ -196,18 +208,21 @@ def train(opt) -> float:
         mloss = torch.zeros(3)
         optimizer.zero_grad()
         for i in range(opt.steps_per_epoch):
-            imgs, targets = blobby_batch(gen, bs, opt.imgsz, nc, device, palette, lb, raw)
             stepping = (i + 1) % accumulate == 0 or i == opt.steps_per_epoch - 1       # :1095-1103
             if dp is not None:
                 # the arena accumulates local gradients over the micro-batches; ranks exchange them once, on the step that applies them
                 dp.reducer.enabled = stepping
                 if stepping:
                     dp.begin()
-            pred = model(imgs)                                                          # :1084-1092
-            loss, loss_items = criterion(pred, targets)
-            loss.backward()
+            for g_r in (emu_gens if emu else [gen]):                                    # (emulation: the ranks' micro-batches in turn)
+                imgs, targets = blobby_batch(g_r, bs, opt.imgsz, nc, device, palette, lb, raw)
+                pred = model(imgs)                                                      # :1084-1092
+                loss, items_r = criterion(pred, targets)
+                loss.backward()
+                if g_r is (emu_gens[0] if emu else gen):
+                    loss_items = items_r
             if stepping:
-                optimizer.step(grad_scale=dp.finish() if dp is not None else 1.0)
+                optimizer.step(grad_scale=dp.finish() if dp is not None else (1.0 / emu if emu else 1.0))
                 optimizer.zero_grad()
             mloss = (mloss * i + torch.tensor(loss_items)) / (i + 1)
         scheduler.step()
@@ -240,6 +255,8 @@ def train(opt) -> float:
     if main and os.path.exists(best):
         mb = ydl.strip_optimizer(best)                                                   # :1229
         print(f"[train_seg] best model saved to {best} ({mb:.1f} MB, optimizer stripped)")
+    pa = optimizer.params_arena[:optimizer.n_params].double()
+    LAST_RUN.update(param_sum=float(pa.sum()), param_abs_sum=float(pa.abs().sum()))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

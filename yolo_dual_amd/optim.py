@@ -196,9 +196,23 @@ class FlatSGDEMA(torch.optim.Optimizer):
         """device table of the CURRENT run structure (as the last backward left the touched flags), created now: call after the
         warm-up steps and before entering a private pool, next to ``ensure_hyper``"""
         sig = self._run_rows(self._runs(commit=False))
-        tab = getattr(self, "_runs_dev", None)
-        if sig and (tab is None or tab[0] != sig):
-            self._runs_dev = (sig, torch.tensor(sig, dtype=torch.int64).to(self.params_arena.device))
+        if sig:
+            self._runs_dev = self._runs_table(sig)
+
+    def _runs_table(self, sig: tuple) -> tuple:
+        """(signature, device table) for a run structure.  Tables are cached per signature and never freed: a recorded launch list or
+        a captured graph holds the raw device pointer of the table it was recorded with, and a later eager step with another
+        structure (a freeze change, a different touched set) must not hand that block back to the allocator"""
+        cache = self.__dict__.setdefault("_runs_cache", {})
+        tab = cache.get(sig)
+        if tab is None:
+            n_tot = self.n_total
+            for off, _nd, _np, n, _gi, _fl in sig:      # rows index the arenas unchecked in the kernel: validate them here
+                if off < 0 or n < 0 or off + n > n_tot:
+                    raise RuntimeError(f"optimizer run table row ({off}, {n}) outside the arenas ({n_tot})")
+            tab = (sig, torch.tensor(sig, dtype=torch.int64).to(self.params_arena.device))
+            cache[sig] = tab
+        return tab
 
     @torch.no_grad()
     def step_device_hyper(self) -> None:
@@ -215,7 +229,7 @@ class FlatSGDEMA(torch.optim.Optimizer):
         sig = rows
         tab = getattr(self, "_runs_dev", None)
         if (tab is None or tab[0] != sig) and rows and L.recorder() is None and not torch.cuda.is_current_stream_capturing():
-            tab = (sig, torch.tensor(rows, dtype=torch.int64).to(pa.device))
+            tab = self._runs_table(sig)
             self._runs_dev = tab
         if tab is not None and tab[0] == sig:
             if rows:

@@ -93,6 +93,9 @@ class GradBucketReducer:
         self._wdt = torch.float32 if wire == "f32" else torch.bfloat16
         self._stage: Dict[int, dict] = {}
         self._post: List = []
+        self._phase1: List = []      # rs_ag: buckets whose reduce-scatter is in flight (handles, post2, fin2)
+        self._phase2: List = []      # rs_ag: buckets whose all-gather is in flight (handles, fin2)
+        self.overlap_phase2 = True   # False: both phases of every bucket in _drain (the round-3 form; kept as the tests' reference)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(bucket_bytes // 4, 1)
@@ -209,7 +212,8 @@ class GradBucketReducer:
             torch.cuda.current_stream().synchronize()
         hs = dist.batch_isend_irecv(ops) if ops else []
 
-        def phase2(st=st, view=view, n=n, chunk=chunk):
+        def post2(st=st, view=view, chunk=chunk):
+            """phase 2 of a bucket, posting half: sum the received pieces, send my reduced piece to every peer (all-gather)"""
             sum_chunks(st["recv"], st["own"], W)                                   # f32 sum in rank order
             to_wire(st["own"], st["send"][me * chunk:(me + 1) * chunk])
             ops2 = []
@@ -220,10 +224,26 @@ class GradBucketReducer:
                 ops2.append(dist.P2POp(dist.irecv, st["send"][r * chunk:(r + 1) * chunk], self._peer(r), self.group))
             if self._host_p2p and view.is_cuda:
                 torch.cuda.current_stream().synchronize()
-            for h in (dist.batch_isend_irecv(ops2) if ops2 else []):
-                h.wait()
+            return dist.batch_isend_irecv(ops2) if ops2 else []
+
+        def fin2(st=st, view=view, n=n):
             from_wire(st["send"][:n], view)                                        # every rank holds the same reduced bucket
-        self._post.append((hs, phase2))
+
+        # The all-gather of bucket k is posted when bucket k + 1 is launched (its reduce-scatter has had a bucket's worth of backward
+        # to complete), not at the end of backward: phase 2 of every bucket but the last overlaps the remaining backward.  The point
+        # is a fixed place in the program, NOT "whenever is_completed() turns true": point-to-point messages between two ranks are
+        # matched in posting order, so every rank must post P1(0) P2(0) P1(1) P2(1) ... in the same order.
+        if self.overlap_phase2:
+            self._advance_phase1()
+        self._phase1.append((hs, post2, fin2))
+
+    def _advance_phase1(self) -> None:
+        """wait for the reduce-scatter of the buckets launched so far and post their all-gathers"""
+        for hs, post2, fin2 in self._phase1:
+            for h in hs:
+                h.wait()              # (RCCL: a stream dependency, not a host wait)
+            self._phase2.append((post2(), fin2))
+        self._phase1 = []
 
     def _peer(self, r: int) -> int:
         return r if self.group is None else dist.get_global_rank(self.group, r)
@@ -237,6 +257,21 @@ class GradBucketReducer:
                 h.wait()
             fn()
         self._post = []
+        if self.overlap_phase2:
+            self._advance_phase1()                 # the last bucket's all-gather
+            for hs2, fin2 in self._phase2:
+                for h in hs2:
+                    h.wait()
+                fin2()
+        else:                                      # serial form (reference for the tests): each bucket's phases back to back
+            for hs, post2, fin2 in self._phase1:
+                for h in hs:
+                    h.wait()
+                for h in post2():
+                    h.wait()
+                fin2()
+            self._phase1 = []
+        self._phase2 = []
 
     # ------------------------------------------------------------------ end of backward
     def finish(self) -> float:

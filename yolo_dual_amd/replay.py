@@ -21,6 +21,7 @@ matches eager afterwards proves nothing in the step depended on un-replayed writ
 from __future__ import annotations
 
 import ctypes
+import time
 import struct
 from typing import List, Optional
 
@@ -185,6 +186,8 @@ class ReplayedTrainStep:
             self._handles = [st.cuda_stream for st in self._prio_streams]
             self.main = self._prio_streams[0]
         self._nbt_per_replay = [bn._nbt_pending - a for bn, a in zip(self._bns, nbt0)]
+        self._runs_tab = getattr(optimizer, "_runs_dev", None)      # the recorded list holds the raw pointer of this table: keep it alive
+        self.host_run_s = 0.0
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------
@@ -244,29 +247,43 @@ class ReplayedTrainStep:
         return self.rec.calls
 
     def step(self):
-        """one training step; returns the (device-resident) [total, ce, overlap] loss scalars"""
+        """one training step; returns the (device-resident) [total, ce, overlap] loss scalars.  ``self.host_run_s`` accumulates the
+        host time spent inside ``ydl_replay_run`` alone (what re-issuing the list costs, net of the optimizer's hyper-parameter ring
+        wait and of the collectives between the segments)"""
         cur = torch.cuda.current_stream()
-        if cur.cuda_stream != self.main.cuda_stream:
-            self.main.wait_stream(cur)
+        foreign = cur.cuda_stream != self.main.cuda_stream
+        if foreign:
+            self.main.wait_stream(cur)                 # whatever the caller enqueued (the batch) precedes the list
         scale = 1.0
+        pc = time.perf_counter
         if self.multi:
             red = self.dp.reducer
             red.begin_step()
             pos = 0
             for cut, bi, st in self._cuts:
+                t0 = pc()
                 self.rec.run(pos, cut)
+                self.host_run_s += pc() - t0
                 with torch.cuda.stream(st):
                     red._launch(bi)                    # overlaps with the remaining segments
                 pos = cut
+            t0 = pc()
             self.rec.run(pos, self._n_fb)
+            self.host_run_s += pc() - t0
             scale = self.dp.finish()
-            self.opt.prepare_step(scale)
+            self.opt.prepare_step(scale)               # H2D of {lr, momentum, wd, scale, EMA decay} on the CURRENT stream ...
+            if foreign:
+                self.main.wait_stream(cur)             # ... which the optimizer segment on the main slot must see
+            t0 = pc()
             self.rec.run(self._n_fb, self._n_all)
+            self.host_run_s += pc() - t0
         else:
-            self.opt.prepare_step(scale)               # H2D of {lr, momentum, wd, scale, EMA decay}: ahead of the list (the main slot waits for it)
-            if self._handles is not None:
-                self.main.wait_stream(cur)
+            self.opt.prepare_step(scale)               # H2D of {lr, momentum, wd, scale, EMA decay} on the CURRENT stream
+            if foreign or self._handles is not None:
+                self.main.wait_stream(cur)             # the list's optimizer kernel reads that vector: order the main slot behind the copy
+            t0 = pc()
             self.rec.run(0, self._n_all, self._handles)
+            self.host_run_s += pc() - t0
         for bn, k in zip(self._bns, self._nbt_per_replay):
             bn._nbt_pending += k
         config.bump_weight_epoch()

@@ -542,7 +542,7 @@ class Tape:
             if out is None:
                 out = self.new(x.N, Cout, Ho, Wo)
                 out.rep = x.rep
-                if virt is None and not x.need and not any(m.trainable()):
+                if virt is None and not x.need and not any(m.trainable()) and (res is None or not res.need):
                     out.need = False      # frozen layer on a prefix that needs no gradient: consumers skip their dgrad into it
             elif (out.N, out.C, out.H, out.W) != (x.N, Cout, Ho, Wo):
                 raise RuntimeError("conv_bn_act: output slice has the wrong shape")
@@ -665,8 +665,9 @@ class Tape:
         def bw():
             if not any(o.is_set() for (_c, _w, o) in parts):
                 return                                   # dead branch: parameters keep grad None
-            if not (x.need or train_w or train_g or train_b) and subs is None:
+            if not (x.need or train_w or train_g or train_b) and subs is None and (res is None or not res.need):
                 return                                   # frozen layer on a frozen prefix: nothing upstream wants a gradient
+                                                         # (a residual operand that does is served by the BN-backward pass below)
             st2 = _stream()
             dy = self.new(x.N, Cout, Ho, Wo)
             # frozen BN parameters (requires_grad False): the sums still exist (dy needs them) but land in a scratch row
