@@ -272,12 +272,15 @@ def main():
             torch.cuda.synchronize()
 
     fence()
+    if rstep is not None:
+        rstep.host_run_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         items = step()
-    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no sync inside the loop)
-    fence()
-    dt = time.perf_counter() - t0
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no sync inside the loop); with the launch-list replay this
+    fence()                                   # includes the optimizer's wait on its 8-deep hyper-parameter ring, i.e. the host being
+    dt = time.perf_counter() - t0             # throttled to the GPU's pace — host_replay_ms_per_step is the time inside ydl_replay_run alone
+    host_replay_ms = rstep.host_run_s / args.steps * 1e3 if rstep is not None else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -329,7 +332,9 @@ def main():
                 ig = [k for k in tj["kernels"] if "igemm" in k["kernel"] or "pw_kernel" in k["kernel"]]
                 n_l = sum(k["launches_per_step"] for k in ig)
                 traffic = {"unit": "MB per launch (conv fwd+dgrad launches: igemm / igemm2 / pw kernels; rocprofv3 --pmc FETCH_SIZE x2 per the "
-                                   "gfx950 note + WRITE_SIZE, " + os.path.basename(tpath) + ")",
+                                   "gfx950 note + WRITE_SIZE)",
+                           "source": "committed profile profiles/" + os.path.basename(tpath) + " (separate --pmc passes of this same command, "
+                                     "collected by tools/collect_profiles.sh; NOT measured in this run)",
                            "value": sum(k["fetch_MB"] + k["write_MB"] for k in ig) / max(n_l, 1)}
             except Exception:
                 traffic = None
@@ -367,6 +372,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic", "launch_mode": mode, "loss": loss_val, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+            "host_replay_ms_per_step": host_replay_ms,
             "config": {"workload": f"{wl['desc']}, fwd+bwd+SGD/EMA step, {args.size}x{args.size}, bs={args.bs}/GPU, "
                                    f"CE+0.5*{wl['loss'].capitalize()}, 12 classes ({wl['base']})", "name": args.workload,
                        "global_batch": args.bs * world, "parallelism": f"dp{world}"},

@@ -134,9 +134,50 @@ def test_replay_keeps_two_streams_and_costs_little_host_time():
             r.step()
         t_replay = (time.perf_counter() - t0) / 5
         torch.cuda.synchronize()
-        print(f"[replay] host time per step: eager {t_eager * 1e3:.2f} ms, launch list {t_replay * 1e3:.2f} ms ({r.launches} calls)")
+        t_run = r.host_run_s / 7           # (2 + 5 steps since the constructor) time inside ydl_replay_run alone
+        print(f"[replay] host time per step: eager {t_eager * 1e3:.2f} ms, launch list {t_replay * 1e3:.2f} ms "
+              f"({t_run * 1e3:.2f} ms inside ydl_replay_run, {r.launches} calls)")
         assert t_replay < 0.5 * t_eager, (t_replay, t_eager)
+        # absolute: re-issuing the ~190 recorded launches (same count at 640^2 bs 16) takes well under 1.5 ms of host time
+        assert t_run < 1.5e-3, t_run
     finally:
+        ydl.set_compute_dtype("bf16")
+
+
+def test_replay_issued_under_another_stream_sees_the_hyper_parameters():
+    """step() called while a stream other than the recording stream is current: the optimizer's hyper-parameter vector (learning rates,
+    momentum, weight decay, gradient scale, EMA decay) is copied on the CALLER's stream and must be ordered in front of the recorded
+    optimizer kernel — with a changing learning rate a stale read shows in the parameters; the trajectory equals the one issued from
+    the recording stream bit for bit"""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import config
+    from yolo_dual_amd.replay import ReplayedTrainStep
+    config.set_deterministic(True)
+    try:
+        res = []
+        for foreign in (False, True):
+            m, opt, crit, xs, ts = _setup("bf16")
+            x, t = xs[0].clone(), ts[0].clone()
+            r = ReplayedTrainStep(m, crit, opt, x, t, warmup=1)
+            other = torch.cuda.Stream()
+            for st in range(5):
+                for g in opt.param_groups:
+                    g["lr"] = 0.01 * (1.0 + st)               # a stale vector would apply the previous step's rate
+                if foreign:
+                    other.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(other):
+                        x.copy_(xs[st % 3]); t.copy_(ts[st % 3])
+                        r.step()
+                    torch.cuda.current_stream().wait_stream(other)
+                else:
+                    x.copy_(xs[st % 3]); t.copy_(ts[st % 3])
+                    r.step()
+            torch.cuda.synchronize()
+            res.append(_state(m, opt))
+        for k, v in res[0].items():
+            assert torch.equal(v, res[1][k]), k
+    finally:
+        config.set_deterministic(None)
         ydl.set_compute_dtype("bf16")
 
 

@@ -211,6 +211,15 @@ def profile_end():
     return out
 
 
+def _bn_bwd_passes(rmode, act, dres) -> int:
+    """tensor passes of one BatchNorm-backward launch, each distinct tensor once: y and dout read, dy written; ReLU also reads the
+    stored output (its mask); a residual operand gets its gradient written by the same launch (read-modify-write when a second writer)"""
+    n = 3 + (1 if act == ACT_RELU else 0)
+    if dres is not None and getattr(dres, "value", dres):
+        n += 1 + (1 if (int(rmode) & RES_GRAD_ACCUMULATE) else 0)
+    return n
+
+
 _LAUNCHES = [0]
 _RECORDER = None        # yolo_dual_amd.replay.Recorder while a step is being recorded into a launch list
 
@@ -254,13 +263,13 @@ def call(name: str, *args):
         g = float(args[11]) * args[12] * es * (2 + (1 if args[7] else 0))
     elif name == "ydl_bn_act_bwd":          # y and dout read once, dy written once (the two-phase kernel reads them twice)
         es = 4 if args[0] == YDL_F32 else 2
-        g = float(args[22]) * args[24] * es * 3
+        g = float(args[22]) * args[24] * es * _bn_bwd_passes(args[12], args[13], args[16])
     elif name == "ydl_bn_act_fwd_sums":
         es = 4 if args[0] == YDL_F32 else 2
         g = float(args[23]) * args[25] * es * (2 + (1 if args[19] else 0))
     elif name == "ydl_bn_act_bwd_sums":
         es = 4 if args[0] == YDL_F32 else 2
-        g = float(args[21]) * args[23] * es * 3
+        g = float(args[21]) * args[23] * es * _bn_bwd_passes(args[11], args[12], args[15])
     elif name in ("ydl_dcnv3_fwd", "ydl_dcnv3_bwd"):
         # algorithmic bytes: input, offsets, masks (and grad_output) read once; output / the three f32 gradients written once
         es = 4 if args[0] == YDL_F32 else 2

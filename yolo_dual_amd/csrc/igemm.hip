@@ -493,7 +493,7 @@ __device__ __forceinline__ void br_fill_coef(const IgemmArgs& p, float* scoef, i
         *(float4*)(scoef + t * 4) = v;
     }
 }
-template <int BM, int BN, int NW, int WP, bool RED = false>
+template <int BM, int BN, int NW, int WP, bool RED = false, bool STATS = true>
 __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)[(BN / (NW / WP)) / 16][BM / (16 * WP)],
                                                 unsigned char* smem, int m0, int n0, int mtile, int c_M, int c_Wg, int c_Hg,
                                                 int c_h0, int c_w0, const float* scoef = nullptr, const bool acc_done = false) {
@@ -537,6 +537,58 @@ __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)
                 }
             }
         }
+    }
+    // ---- BN partial statistics (before the transpose: the scratch is free, and the sums leave their registers at once).  Plain
+    // per-channel (sum, sum of squares) of the tile in f32: per lane over its PT pixels, over the 16 pixel lanes of a row group by DPP
+    // row rotations (one v_add_f32_dpp each, no LDS round trips), over the pixel waves through LDS.  Throughput mode adds them to the
+    // replica rows with f32 atomics; the partial-row contract (deterministic mode) gets (sum, M2 = sum of squares - sum^2 / n) of the
+    // block — over at most BM = 128 bf16-precision values the cancellation costs (1 + mean^2 / var) x 1e-7 relative, far below the
+    // storage precision of this (bf16-only) kernel family.  The block-local (mean, M2) Chan merge this replaces (34 ds_bpermute round
+    // trips and ~250 VALU instructions behind the main loop of every tile) cost 7..18 % of the forward time of the ring layers.
+    if (STATS && p.stats != nullptr) {
+        float* sred = (float*)smem;                    // [WP][BN][2]
+        auto row_sum = [](float v) {
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));     // row_ror:8
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));     // row_ror:4
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));     // row_ror:2
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));     // row_ror:1
+            return v;
+        };
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float a[4], b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = 0.f; b[e] = 0.f;
+#pragma unroll
+                for (int j = 0; j < PT; ++j) { const float v = acc[c][j][e]; a[e] += v; b[e] += v * v; }    // rows beyond M are exact zeros
+                a[e] = row_sum(a[e]);
+                b[e] = row_sum(b[e]);
+            }
+            if (lrow == 0) {
+                const int ch = wc * BNW + c * 16 + lgrp * 4;
+                *(float4*)(sred + (wp * BN + ch) * 2) = make_float4(a[0], b[0], a[1], b[1]);
+                *(float4*)(sred + (wp * BN + ch) * 2 + 4) = make_float4(a[2], b[2], a[3], b[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // one channel group at a time: eight reduction chains, not thirty-two
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < p.Cout) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WP; ++w) { const float2 v = *(const float2*)(sred + (w * BN + t) * 2); a += v.x; b += v.y; }
+            if (p.stats_atomic) {
+                float* dst = p.stats + (size_t)(mtile & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
+                atomicAdd(dst + n0 + t, a);
+                atomicAdd(dst + p.stats_ld + n0 + t, b);
+            } else {
+                const float nvalid = (float)min(BM, c_M - m0);
+                float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
+                dst[n0 + t] = a;
+                dst[p.stats_ld + n0 + t] = fmaxf(b - a * a / nvalid, 0.f);
+            }
+        }
+        __syncthreads();                               // the sums have been read: the transposed tile may overwrite them
     }
     // ---- transpose through LDS
 #pragma unroll
@@ -652,107 +704,6 @@ __device__ __forceinline__ void igemm2_epilogue(const IgemmArgs& p, f32x4 (&acc)
                     atomicAdd(dst + p.br.cp[sgm] + (c - p.br.c0[sgm]), b);
                 }
             }
-        }
-    }
-    if (p.stats == nullptr) return;
-    // ---- BN partial statistics, one pass
-    constexpr int NV = 4 * CT;
-    const int nvalid = min(BM, c_M - m0);
-    float cnt = 0.f;
-#pragma unroll
-    for (int j = 0; j < PT; ++j) cnt += (wp * (BM / WP) + j * 16 + lrow) < nvalid ? 1.f : 0.f;
-    float mean[NV], m2[NV];
-    {
-        const float rn = cnt > 0.f ? 1.f / cnt : 0.f;
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float s1 = 0.f;
-#pragma unroll
-                for (int j = 0; j < PT; ++j) s1 += acc[c][j][e];          // rows beyond M are exact zeros
-                const float mu = s1 * rn;
-                float q = 0.f;
-#pragma unroll
-                for (int j = 0; j < PT; ++j) {
-                    const bool ok = (wp * (BM / WP) + j * 16 + lrow) < nvalid;
-                    const float d = acc[c][j][e] - mu;
-                    q += ok ? d * d : 0.f;
-                }
-                mean[c * 4 + e] = mu;
-                m2[c * 4 + e] = q;
-            }
-    }
-    int live = NV;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int mask = 1 << s;
-        const bool hi = (lrow >> s) & 1;
-        const float cnt_o = __shfl_xor(cnt, mask, 64);
-        const float tot = cnt + cnt_o;
-        const float rt = tot > 0.f ? 1.f / tot : 0.f;
-        const float fo = cnt_o * rt, fx = cnt * cnt_o * rt;
-        if (live > 1) {
-#pragma unroll
-            for (int k = 0; k < NV / 2; ++k)
-                if (k < live / 2) {
-                    const float km = hi ? mean[2 * k + 1] : mean[2 * k], sm = hi ? mean[2 * k] : mean[2 * k + 1];
-                    const float kq = hi ? m2[2 * k + 1] : m2[2 * k], sq = hi ? m2[2 * k] : m2[2 * k + 1];
-                    const float om = __shfl_xor(sm, mask, 64), oq = __shfl_xor(sq, mask, 64);
-                    const float d = om - km;
-                    mean[k] = km + d * fo;
-                    m2[k] = kq + oq + d * d * fx;
-                }
-            live >>= 1;
-        } else {
-            const float om = __shfl_xor(mean[0], mask, 64), oq = __shfl_xor(m2[0], mask, 64);
-            const float d = om - mean[0];
-            mean[0] = mean[0] + d * fo;
-            m2[0] = m2[0] + oq + d * d * fx;
-        }
-        cnt = tot;
-    }
-    // slot tt of lane lrow holds value index (tt << 4 | lrow) (NV >= 16) or (lrow & (NV-1)) in slot 0; channel of index idx =
-    // wc*BNW + (idx>>2)*16 + lgrp*4 + (idx&3)
-    __syncthreads();                               // the store pass has read the transposed tile
-    float* sred = (float*)smem;                    // [WP][BN][2] (mean, M2), then [WP] counts
-    float* scnt = sred + WP * BN * 2;
-    if (NV >= 16) {
-#pragma unroll
-        for (int tt = 0; tt < (NV >= 16 ? NV / 16 : 1); ++tt) {
-            const int idx = (tt << 4) | lrow;
-            const int ch = wc * BNW + (idx >> 2) * 16 + lgrp * 4 + (idx & 3);
-            sred[(wp * BN + ch) * 2] = mean[tt];
-            sred[(wp * BN + ch) * 2 + 1] = m2[tt];
-        }
-    } else if (lrow < NV) {
-        const int ch = wc * BNW + (lrow >> 2) * 16 + lgrp * 4 + (lrow & 3);
-        sred[(wp * BN + ch) * 2] = mean[0];
-        sred[(wp * BN + ch) * 2 + 1] = m2[0];
-    }
-    if (lane == 0 && wc == 0) scnt[wp] = cnt;
-    __syncthreads();
-    if (t < BN && n0 + t < p.Cout) {
-        float n = 0.f, mu = 0.f, q2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WP; ++w) {
-            const float nb = scnt[w];
-            const float mb = sred[(w * BN + t) * 2], qb = sred[(w * BN + t) * 2 + 1];
-            const float tot = n + nb;
-            const float rt = tot > 0.f ? 1.f / tot : 0.f;
-            const float d = mb - mu;
-            mu = mu + d * nb * rt;
-            q2 = q2 + qb + d * d * n * nb * rt;
-            n = tot;
-        }
-        if (p.stats_atomic) {
-            float* dst = p.stats + (size_t)(mtile & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
-            atomicAdd(dst + n0 + t, mu * n);
-            atomicAdd(dst + p.stats_ld + n0 + t, q2 + n * mu * mu);
-        } else {
-            float* dst = p.stats + (size_t)mtile * 2 * p.stats_ld;
-            dst[n0 + t] = mu * n;
-            dst[p.stats_ld + n0 + t] = q2;
         }
     }
 }
@@ -1711,7 +1662,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void igemm2s_kernel(const IgemmArg
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q) __syncthreads();                                // the previous class's store pass has read the scratch
-        igemm2_epilogue<BM, BN, NW, WP>(p, acc[q], smem, 0, n0, mtile, BM, 16, 8, n * p.Ho + 2 * i0 + (q >> 1), 2 * j0 + (q & 1), nullptr,
+        igemm2_epilogue<BM, BN, NW, WP, false, false>(p, acc[q], smem, 0, n0, mtile, BM, 16, 8, n * p.Ho + 2 * i0 + (q >> 1), 2 * j0 + (q & 1), nullptr,
                                         true);                 // (ACC: the previous contents are in the accumulators already; otherwise the
                                                                //  launcher guarantees accumulate == 0: no register-layout pre-pass either way)
     }
