@@ -252,12 +252,17 @@ def _cfg_dcn():
     return yaml.safe_load(open(os.path.join(os.path.dirname(CFG), "yolov9_dcnv3_seg.yaml")))
 
 
+@pytest.mark.parametrize("init", ["random", "reference"])
 @pytest.mark.parametrize("hw,bs", [((64, 64), 2), ((96, 96), 2)])
-def test_config5_dcnv3_model_matches_the_oracle(hw, bs):
+def test_config5_dcnv3_model_matches_the_oracle(hw, bs, init):
     """BASELINE configs[4] as its string reads — YOLOv9 backbone with C3-DCN from models/ops_dcnv3 (cfg/yolov9_dcnv3_seg.yaml:
     C3_DCNV3 of "common and yolo.py":27-38 around the DCNv3 module, modules/dcnv3.py:50-136) — as a WHOLE model in parity mode
-    against the CPU oracle (oracle.ref_cpu.script_model_forward resolves C3_DCNV3 with the reference's pure-PyTorch core):
-    probabilities, loss, every live gradient, same grad-None set (bounds: see the comment at the assertions)."""
+    against the CPU oracle (oracle.ref_cpu.script_model_forward resolves C3_DCNV3 with the reference's pure-PyTorch core), anchored
+    on a FLOAT64 run of the same oracle: what fp32 can reproduce of this model is measured, not assumed.
+    ``init = "reference"``: the offset / mask projections start at zero as the reference initialises them (modules/dcnv3.py:101-107),
+    every sampling point sits ON the integer grid and the probabilities are held to the north star's 1e-4;
+    ``init = "random"``: random offset weights put sampling points next to the integer grid, where the bilinear weights have kinks —
+    there the f32 oracle itself is 2.4e-4 from its f64 run, and this path is required to be no more than twice as far."""
     import yolo_dual_amd as ydl
     from tests.util import l2_err, rel_err
     cfg = _cfg_dcn()
@@ -269,13 +274,23 @@ def test_config5_dcnv3_model_matches_the_oracle(hw, bs):
     sd = {k: (torch.zeros(s) if not k.endswith("num_batches_tracked") else torch.zeros((), dtype=torch.int64))
           for k, s in shapes.items()}
     fill_state_dict(sd, 31, bn_stats=False)
+    if init == "reference":
+        for k in sd:
+            if k.endswith((".offset.weight", ".offset.bias", ".mask.weight", ".mask.bias")):
+                sd[k].zero_()
     pnames = [k for k in sd if k.endswith(".weight") or k.endswith(".bias")]
-    ps = {k: sd[k].detach().clone().requires_grad_(True) for k in pnames}
-    run = dict(sd)
-    run.update(ps)
-    out = R.script_model_forward(run, cfg, x, (H, W), family="v9")
-    total, _, _ = R.seg_loss(out, t, CW, "dice")
-    total.backward()
+
+    def oracle(dt):
+        ps_ = {k: sd[k].detach().clone().to(dt).requires_grad_(True) for k in pnames}
+        run = {k: (v.clone().to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+        run.update(ps_)
+        out_ = R.script_model_forward(run, cfg, x.to(dt), (H, W), family="v9")
+        total_, _, _ = R.seg_loss(out_, t, CW.to(dt), "dice")
+        total_.backward()
+        return out_.detach(), float(total_.detach()), ps_
+
+    out, total, ps = oracle(torch.float32)
+    out64, total64, ps64 = oracle(torch.float64)
     ydl.set_compute_dtype("f32")
     try:
         m = ydl.YOLOv9Seg(cfg)
@@ -288,28 +303,37 @@ def test_config5_dcnv3_model_matches_the_oracle(hw, bs):
         tot2, items = crit(o2, t.cuda())
         tot2.backward()
         assert list(o2.shape) == list(out.shape)
-        # What fp32 can reproduce of THIS model at these sizes, measured on the oracle itself (f32 run vs f64 run of
-        # oracle.ref_cpu, same weights): probabilities 2.4e-4 / 1.7e-4 max-relative at 64 / 96 pixels, loss 1e-7, parameter gradients
-        # in relative L2 median 3.4e-3 / 9.1e-3, maximum 1.1e-2 / 1.4e-2 (random offset weights put sampling points next to the
-        # integer grid, where the bilinear weights have kinks; BatchNorms of the 2x2 .. 3x3 maps see 8-18 values).  This path against
-        # the f32 oracle measures a median of 4.0e-3 / 6.8e-3.
-        # Bounds: 4x the oracle's own on the probabilities, the loss (an average) stays at 1e-4, gradients 4e-2 with a median below 2e-2.
-        assert rel_err(o2.detach().cpu(), out.detach()) < 1e-3
-        assert abs(items[0] - float(total)) <= 1e-4 * abs(float(total))
+        got = o2.detach().cpu()
+        e_oracle, e_hip, e_mutual = rel_err(out, out64), rel_err(got, out64), rel_err(got, out)
+        print(f"[dcn parity {init} {H}x{W}] probabilities vs f64: oracle f32 {e_oracle:.2e}, HIP f32 {e_hip:.2e}; HIP vs oracle f32 {e_mutual:.2e}")
+        # probabilities: no further from the float64 result than twice the f32 oracle's own distance (floor: 2e-5 = a few f32 ulps
+        # through ~60 layers); with the reference's initialisation additionally the north star's 1e-4 against the f32 oracle
+        assert e_hip <= max(2.0 * e_oracle, 2e-5), (e_hip, e_oracle)
+        if init == "reference":
+            assert e_mutual < 1e-4, e_mutual
+        assert abs(items[0] - total64) <= 1e-4 * abs(total64)
         named = dict(m.named_parameters())
         none_ref = sorted(k for k in pnames if ps[k].grad is None)
         none_got = sorted(k for k, p in named.items() if not getattr(p, "_ydl_touched", False))
         assert none_got == none_ref
-        # (a DCNv3 output_proj.bias sits in front of the 1x1 cv3 + train-mode BN of its C3: a per-channel constant there cancels, so
-        # its gradient is mathematically zero and the oracle's value is rounding noise — such entries are only held to "tiny")
-        gscale = max(float(ps[k].grad.abs().max()) for k in pnames if ps[k].grad is not None)
-        tiny = [k for k in pnames if ps[k].grad is not None and float(ps[k].grad.abs().max()) < 1e-4 * gscale]
+        # gradients, per tensor, against the float64 run (a DCNv3 output_proj.bias sits in front of the 1x1 cv3 + train-mode BN of its
+        # C3: a per-channel constant there cancels, so its gradient is mathematically zero and any f32 value is rounding noise — such
+        # entries are only held to "tiny"; with the reference's zero offset / mask weights the same holds for nothing else)
+        gscale = max(float(ps64[k].grad.abs().max()) for k in pnames if ps64[k].grad is not None)
+        tiny = [k for k in pnames if ps64[k].grad is not None and float(ps64[k].grad.abs().max()) < 1e-6 * gscale]
         for k in tiny:
             assert float(named[k].grad.abs().max()) < 1e-3 * gscale, k
-        errs = {k: l2_err(named[k].grad.detach().cpu(), ps[k].grad) for k in pnames if ps[k].grad is not None and k not in tiny}
-        bad = {k: e for k, e in errs.items() if e > 4e-2}
-        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
-        assert float(np.median(list(errs.values()))) < 2e-2, float(np.median(list(errs.values())))
+        live = [k for k in pnames if ps64[k].grad is not None and k not in tiny]
+        eo = {k: l2_err(ps[k].grad, ps64[k].grad) for k in live}
+        eh = {k: l2_err(named[k].grad.detach().cpu(), ps64[k].grad) for k in live}
+        med_o, med_h = float(np.median(list(eo.values()))), float(np.median(list(eh.values())))
+        print(f"[dcn parity {init} {H}x{W}] gradients vs f64 (relative L2): oracle f32 median {med_o:.2e} max {max(eo.values()):.2e}, "
+              f"HIP f32 median {med_h:.2e} max {max(eh.values()):.2e}")
+        # per tensor: twice the f32 oracle's distance from the f64 gradient, with a floor of twice the oracle's MEDIAN distance (a tensor
+        # the oracle happens to get almost exactly is not a bound); overall: the medians within a factor of two
+        bad = {k: (eh[k], eo[k]) for k in live if eh[k] > max(2.0 * eo[k], 2.0 * med_o, 1e-5)}
+        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:5]
+        assert med_h <= max(2.0 * med_o, 1e-5), (med_h, med_o)
     finally:
         ydl.set_compute_dtype("bf16")
 

@@ -3289,8 +3289,10 @@ static WgradPlan wgrad_plan(const ydl_conv_geom* g, int dtype) {
     if (dtype == YDL_BF16 && g_wgrad_tr == 1 && M < wg2_min_m && onewave && Kc % 8 == 0) {
         const int TCO = g->Cout > 64 ? 128 : 64;
         const long tiles = (long)((ntaps * Kc + 127) / 128) * ((g->Cout + TCO - 1) / TCO);
-        const long sp = 512 / tiles;
-        mid = sp >= 1 && tiles * sp >= 410 && (M + 63) / 64 >= 4 * sp && (ntaps > 1 || onewave == 2);
+        static const long slots = getenv("YDL_WG2_MIDSLOTS") ? atol(getenv("YDL_WG2_MIDSLOTS")) : 512;      // tuning
+        static const long minfill = getenv("YDL_WG2_MIDMIN") ? atol(getenv("YDL_WG2_MIDMIN")) : 410;
+        const long sp = slots / tiles;
+        mid = sp >= 1 && tiles * sp >= minfill && (M + 63) / 64 >= 4 * sp && (ntaps > 1 || onewave == 2);
     }
     if (dtype == YDL_BF16 && g_wgrad_tr == 1 && (M >= wg2_min_m || mid)) {
         const int TCO = g->Cout > 64 ? 128 : 64;
@@ -3300,7 +3302,8 @@ static WgradPlan wgrad_plan(const ydl_conv_geom* g, int dtype) {
         const long tiles = (long)pl.jtiles * pl.ctiles;
         const int stages = (M + 63) / 64;
         if (mid) {
-            int splits = (int)(512 / tiles);
+            static const long slots = getenv("YDL_WG2_MIDSLOTS") ? atol(getenv("YDL_WG2_MIDSLOTS")) : 512;
+            int splits = (int)(slots / tiles);
             const int per = (stages + splits - 1) / splits;
             pl.chunk = per * 64;
             pl.splits = (M + pl.chunk - 1) / pl.chunk;
@@ -3373,11 +3376,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 3 = bf16 LDS-DMA ring kernel (igemm2) for the MFMA-bound layers: 1 (default) on, 0 off (igemm_kernel everywhere)
 //              key 8 = patch-form kernel for the 3x3 / stride-1 layers (igemm2h_kernel): 1 (default) on, 0 ring kernel
 //              key 9 = fused-parity kernel for the k3 s2 p1 data gradients (igemm2s_kernel): 1 (default) on, 0 ring kernel
+//              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
 //              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
 // Process-wide and test-only: they change launch geometry, so callers that cache ydl_conv_fwd_grid_m/... must drop the cache
 // after a change (yolo_dual_amd._lib.debug_set does).
+extern int g_resize_int;       // spatial.hip
 extern "C" void ydl_debug_set(int key, int val) {
     if (key == 0) g_wgrad_tr = val;
     if (key == 1) g_pw_enabled = val;
@@ -3388,6 +3393,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 6) g_ring_persist = val;
     if (key == 8) g_halo = val;
     if (key == 9) g_s2fused = val;
+    if (key == 10) g_resize_int = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {

@@ -3,6 +3,7 @@
 // Index arithmetic restates ATen's (UpSample.h area_pixel_compute_source_index / nearest_idx) with explicit
 // round-to-nearest f32 ops so the compiler cannot contract them into FMAs: indices are bit-exact vs the CPU.
 #include "common.h"
+#include <stdlib.h>
 
 static inline int sgrid(long long total) {
     long long b = (total + 255) / 256;
@@ -464,6 +465,62 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(int mode, const T* __re
     }
 }
 
+// Bilinear (align_corners = False) up-sampling by an INTEGER factor S: the outputs that reference input index i are exactly
+// S*i - S/2 ... S*i + S + S/2 - 1 (2S candidates per axis, clamped to the image), so the gather backward needs 2S + 2S index/weight
+// derivations per element instead of one per candidate PAIR of the generic kernel above (a 16 x 16 candidate window at S = 4: the
+// generic form is VALU-bound, 82 us for the 128-channel 160^2 -> 40^2 gradient of BASELINE config 2).  Index and weights still come
+// from lin_src, i.e. the transpose of the forward kernel's arithmetic, border clamps included.
+template <typename T, int S>
+__global__ __launch_bounds__(256) void resize_bwd_int_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int accumulate,
+                                                             int N, int Hi, int Wi, int Cp, float sh, float sw) {
+    constexpr int V = ET<T>::V;
+    constexpr int NC = 2 * S;
+    const int Ho = Hi * S, Wo = Wi * S;
+    const int cpp = Cp / V;
+    const long long total = (long long)N * Hi * Wi * cpp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % cpp);
+        const long long pix = i / cpp;
+        const int iw = (int)(pix % Wi);
+        const long long t2 = pix / Wi;
+        const int ih = (int)(t2 % Hi);
+        const int n = (int)(t2 / Hi);
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = 0.f;
+        if (accumulate) unpack16<T>(*(const uint4*)(dx + (size_t)pix * lddx + cq * V), g);
+        float wwv[NC];
+#pragma unroll
+        for (int b = 0; b < NC; ++b) {
+            const int wo = S * iw - S / 2 + b;
+            float ww = 0.f;
+            if ((unsigned)wo < (unsigned)Wo) { const Lin l = lin_src(wo, sw, Wi, false); ww = (l.i0 == iw ? l.w0 : 0.f) + (l.i1 == iw ? l.w1 : 0.f); }
+            wwv[b] = ww;
+        }
+        const T* db = dy + (size_t)n * Ho * Wo * lddy + cq * V;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const int ho = S * ih - S / 2 + a;
+            if ((unsigned)ho >= (unsigned)Ho) continue;
+            const Lin l = lin_src(ho, sh, Hi, false);
+            const float wh = (l.i0 == ih ? l.w0 : 0.f) + (l.i1 == ih ? l.w1 : 0.f);
+            if (wh == 0.f) continue;
+#pragma unroll
+            for (int b = 0; b < NC; ++b) {
+                const int wo = S * iw - S / 2 + b;
+                if (wwv[b] == 0.f) continue;             // (also every column outside the image)
+                float d[V];
+                unpack16<T>(*(const uint4*)(db + ((size_t)ho * Wo + wo) * lddy), d);
+                const float wgt = wh * wwv[b];
+#pragma unroll
+                for (int e = 0; e < V; ++e) g[e] += wgt * d[e];
+            }
+        }
+        *(uint4*)(dx + (size_t)pix * lddx + cq * V) = pack16<T>(g);
+    }
+}
+
+int g_resize_int = 1;          // ydl_debug_set key 10: 0 = the generic gather backward also for integer scale factors (tests)
 static inline float axis_scale(int mode, int in, int out, float given) {
     if (mode == 2) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
     if (given > 0.f) return given;
@@ -491,6 +548,19 @@ extern "C" int ydl_resize_bwd(int dtype, int mode, const void* dy, int lddy, voi
     float sh = axis_scale(mode, Hi, Ho, scale_h), sw = axis_scale(mode, Wi, Wo, scale_w);
     hipStream_t st = (hipStream_t)stream;
     int grid = sgrid((long long)N * Hi * Wi * (Cp / V));
+    if (g_resize_int && mode == 1 && Ho == Wo / Wi * Hi && Wo % Wi == 0 && (Wo / Wi == 2 || Wo / Wi == 4) && Ho == Hi * (Wo / Wi)) {
+        const int S = Wo / Wi;
+        // (the accumulation order over the candidates equals the generic kernel's: rows outer, columns inner, ascending)
+        if (dtype == YDL_F32) {
+            if (S == 2) resize_bwd_int_kernel<float, 2><<<grid, 256, 0, st>>>((const float*)dy, lddy, (float*)dx, lddx, accumulate, N, Hi, Wi, Cp, sh, sw);
+            else resize_bwd_int_kernel<float, 4><<<grid, 256, 0, st>>>((const float*)dy, lddy, (float*)dx, lddx, accumulate, N, Hi, Wi, Cp, sh, sw);
+        } else {
+            if (S == 2) resize_bwd_int_kernel<bf16_t, 2><<<grid, 256, 0, st>>>((const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate, N, Hi, Wi, Cp, sh, sw);
+            else resize_bwd_int_kernel<bf16_t, 4><<<grid, 256, 0, st>>>((const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate, N, Hi, Wi, Cp, sh, sw);
+        }
+        YDL_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == YDL_F32) resize_bwd_kernel<float><<<grid, 256, 0, st>>>(mode, (const float*)dy, lddy, (float*)dx, lddx, accumulate, N, Hi, Wi, Ho, Wo, Cp, sh, sw);
     else resize_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(mode, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate, N, Hi, Wi, Ho, Wo, Cp, sh, sw);
     YDL_LAUNCH_CHECK();
