@@ -139,6 +139,46 @@ def test_gam(mode):
     _run(m, g, mode)
 
 
+def test_gam_bf16_against_the_oracle_at_a_batch_of_64():
+    """GAM (seg_diceloss_yolov9.py:475-510) in throughput mode with a bound: at batch 64 its pooled branches run BatchNorm over 64
+    values per channel (the golden fixture has 2, where bf16 rounding is amplified without bound).  Reference = oracle.ref_cpu.gam
+    in f32 on the bf16-rounded input and weights; output 3e-2 and gradients 0.1 in relative L2 (the block is x * sigmoid(gate):
+    a bf16-rounded gate moves every element of a channel together)."""
+    import numpy as np
+    import yolo_dual_amd as ydl
+    from oracle import ref_cpu as R
+    from oracle.fill import fill_state_dict
+    from tests.util import l2_err
+    ydl.set_compute_dtype("bf16")
+    C, N, H, W = 64, 64, 8, 8
+    m = ydl.GAM(C)
+    sd = m.state_dict()
+    fill_state_dict(sd, 21, bn_stats=False)
+    for k in sd:
+        if sd[k].dim() == 4:
+            sd[k] = sd[k].bfloat16().float()
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy((rs.standard_normal((N, C, H, W)) + 0.2).astype(np.float32)).bfloat16().float()
+    gup = torch.from_numpy(rs.standard_normal((N, C, H, W)).astype(np.float32))
+    xg = x.cuda().requires_grad_(True)
+    out = m(xg)
+    (out * gup.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    run = {"g." + k: v.clone() for k, v in sd.items()}
+    run.update({"g." + k: v for k, v in ps.items()})
+    xr = x.clone().requires_grad_(True)
+    o = R.gam(run, "g", xr)
+    (o * gup).sum().backward()
+    assert l2_err(out.detach().cpu(), o.detach()) < 3e-2, l2_err(out.detach().cpu(), o.detach())
+    assert l2_err(xg.grad.detach().cpu(), xr.grad) < 0.1, l2_err(xg.grad.detach().cpu(), xr.grad)
+    named = dict(m.named_parameters())
+    errs = {k: l2_err(named[k].grad.detach().float().cpu(), p.grad) for k, p in ps.items() if p.grad is not None}
+    assert errs and max(errs.values()) < 0.1, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+
+
 @pytest.mark.parametrize("name", ["r18_basic", "r18_basic_down", "r50_bneck", "r50_bneck_down"])
 def test_resnet_blocks(name, mode):
     import yolo_dual_amd as ydl

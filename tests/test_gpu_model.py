@@ -23,13 +23,17 @@ def _cfg(name, swap):
     return cfg
 
 
-def _train_check(g, model, crit, mode, steps=2, lr=0.01, f32_grad_tol=2e-3, later_loss_tol=None, f32_out_tol=1e-4):
+def _train_check(g, model, crit, mode, steps=2, lr=0.01, f32_grad_tol=2e-3, later_loss_tol=None, f32_out_tol=1e-4,
+                 bf16_out_tol=0.35, bf16_grad_tol=0.15):
     import yolo_dual_amd as ydl
     ydl.set_compute_dtype(mode)
-    # bf16 at this toy size (64x64, batch 2: the deepest BatchNorms see 8 values per channel) only checks the loss and
-    # the dead-parameter set; bf16 accuracy at a realistic size is test_bf16_tracks_f32 below
+    # bf16 at this toy size (64x64, batch 2: the deepest BatchNorms see 8 values per channel): loss 5e-2, sampled logits
+    # ``bf16_out_tol`` max-relative, every gradient NORM within ``bf16_grad_tol`` of the reference's — about twice what was measured
+    # on MI355X (YOLOv5Seg: logits 0.17, gradient norms median 0.010 / max 0.062; the ill-conditioned yaml ResNet50, whose f32
+    # run is itself 1.6e-2 off on single norms: logits 0.77, norms median 0.16 / max 0.38); per-layer bf16 accuracy at a realistic
+    # size is test_bf16_tracks_f32 below
     tol = dict(f32=dict(out=f32_out_tol, loss=1e-4, gn=f32_grad_tol, fin=f32_grad_tol),
-               bf16=dict(out=None, loss=5e-2, gn=None, fin=None))[mode]
+               bf16=dict(out=bf16_out_tol, loss=5e-2, gn=bf16_grad_tol, fin=None))[mode]
     sd = model.state_dict()
     fill_state_dict(sd, 1234, bn_stats=False)
     model.load_state_dict(sd)
@@ -46,6 +50,10 @@ def _train_check(g, model, crit, mode, steps=2, lr=0.01, f32_grad_tol=2e-3, late
             assert list(out.shape) == [int(v) for v in g.flat["out_shape"]]
             vals = out.detach().flatten()[g.t("out_idx").cuda()].cpu()
             e = rel_err(vals, g.t("out_vals"))
+            if os.environ.get("YDL_TEST_PRINT"):
+                named_ = dict(model.named_parameters())
+                gn_ = [abs(float(named_[k].grad.double().norm()) - n) / max(n, 1e-7) for k, n in zip(g.strs("grad_names"), g.flat["grad_norms"])]
+                print(f"[train_check {g.name} {mode}] logits rel {e:.3e}; grad-norm rel err median {float(np.median(gn_)):.3e} max {max(gn_):.3e}")
             assert tol["out"] is None or e < tol["out"], ("logits", e)
             named = dict(model.named_parameters())
             none = sorted(k for k, p in named.items() if not getattr(p, "_ydl_touched", False))
@@ -125,7 +133,8 @@ def test_resnet50_yaml_trajectory(mode):
     # all pixels, still holds 1e-4.  Gradient norms: the f32 oracle with every weight scaled by (1 + 1e-7) moves the layer1 / layer2
     # BatchNorm gradient norms of this fixture by up to 1.5e-2 (backbone.1.layer.0.conv2.bn.bias), the f64 oracle by 1.3e-2 — ReLU
     # masks flip under BatchNorms that see 8..128 values.  The HIP path differs by up to 1.6e-2 on the same entries: bound 3e-2.
-    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode, f32_grad_tol=3e-2, later_loss_tol=1e-3, f32_out_tol=1e-3)
+    _train_check(g, m, ydl.SegmentationLoss(12, 0.0, CW, "dice"), mode, f32_grad_tol=3e-2, later_loss_tol=1e-3, f32_out_tol=1e-3,
+                 bf16_out_tol=1.6, bf16_grad_tol=0.8)
 
 
 @pytest.mark.parametrize("mode", ["f32"])
@@ -139,8 +148,13 @@ def test_yolov9seg_trajectory(mode):
 
 
 def test_bf16_tracks_f32():
-    """throughput mode vs parity mode of the same kernels at a realistic size (256x256, batch 4): probabilities and
-    loss of the bf16 path stay close to the f32 path (which is pinned to the reference at 1e-4)."""
+    """throughput mode vs parity mode of the same kernels at a realistic size (256x256, batch 4; the f32 path is pinned to the
+    reference at 1e-4): probabilities, loss and EVERY parameter gradient, per layer.  Measured on MI355X (tools/bf16_layer_err.py
+    prints the table): relative L2 of the bf16 gradient from the f32 one is 0.003-0.06 at the last layer, 0.05-0.13 through the
+    head down to the SPPF's second conv, and 0.24-0.32 for everything behind the SPPF's max-pools (bf16 rounding re-routes
+    arg-max elements there), flat from backbone.9.cv1 to the stem — it does not compound per layer.  Bounds: 1.5x the measured
+    worst of each group.  (Even the last layer's weight gradient is at 5 %: BatchNorm's backward removes the mean and the
+    x-hat component of dz, the remainder is small against the bf16-rounded operands it is computed from.)"""
     import yolo_dual_amd as ydl
     from tests.util import l2_err
     res = {}
@@ -159,11 +173,24 @@ def test_bf16_tracks_f32():
         out = m(x)
         total, items = crit(out, t)
         total.backward()
-        res[mode] = (out.detach().float().cpu(), items, m.backbone[0].conv.weight.grad.detach().float().cpu().clone())
+        res[mode] = (out.detach().float().cpu(), items,
+                     {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if getattr(p, "_ydl_touched", False)})
     ydl.set_compute_dtype("bf16")
-    assert l2_err(res["bf16"][0], res["f32"][0]) < 0.1
-    assert abs(res["bf16"][1][0] - res["f32"][1][0]) <= 1e-2 * abs(res["f32"][1][0])
-    assert l2_err(res["bf16"][2], res["f32"][2]) < 0.4        # stem weight gradient: the longest bf16 chain
+    assert sorted(res["bf16"][2]) == sorted(res["f32"][2])
+    assert l2_err(res["bf16"][0], res["f32"][0]) < 0.09                           # measured 0.062
+    assert abs(res["bf16"][1][0] - res["f32"][1][0]) <= 1e-3 * abs(res["f32"][1][0])      # measured 1e-5
+    errs = {k: l2_err(res["bf16"][2][k], res["f32"][2][k]) for k in res["f32"][2]}
+
+    def bound(k):
+        if k.startswith("head.17."):
+            return 0.09                                                            # measured <= 0.055
+        if k.startswith("head.") or k.startswith("backbone.9.cv2."):
+            return 0.2                                                             # measured <= 0.133
+        return 0.45                                                                # behind the max-pools: measured <= 0.32
+    bad = {k: (e, bound(k)) for k, e in errs.items() if e > bound(k)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6]
+    back = [e for k, e in errs.items() if k.startswith("backbone.") and not k.startswith("backbone.9.cv2.")]
+    assert float(np.median(back)) < 0.35, float(np.median(back))                  # measured 0.265
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96, 20, 24), (2, 64, 64, 320, 328)])
