@@ -206,6 +206,12 @@ int ydl_resize_fwd(int dtype, int mode, const void* x, int ldx, void* y, int ldy
                    int N, int Hi, int Wi, int Ho, int Wo, int C, float scale_h, float scale_w, void* stream);
 int ydl_resize_bwd(int dtype, int mode, const void* dy, int lddy, void* dx, int lddx, int accumulate,
                    int N, int Hi, int Wi, int Ho, int Wo, int C, float scale_h, float scale_w, void* stream);
+/* y += resize(x) (same modes and index arithmetic as ydl_resize_fwd); with ``sums`` != NULL also adds the per-channel (sum, sum of
+ * squares) of the result to BatchNorm replica rows sums[YDL_BN_REPLICAS][2][sums_ld], exactly like ydl_conv_fwd_sums' epilogues: the
+ * last launch of a 1x1 Conv over the auto-aligned Concat [a, resize(b)] (seg_diceloss_yolov5.py:484-507 + :388-409) evaluated as
+ * conv_a(a) + resize(conv_b(b)) */
+int ydl_resize_acc_sums(int dtype, int mode, const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo,
+                        int C, float scale_h, float scale_w, float* sums, int sums_ld, void* stream);
 /* strided channel-slice copy / add:  dst[:, 0:C] (op)= src[:, 0:C] */
 int ydl_copy2d(int dtype, const void* src, int lds, void* dst, int ldd, int64_t npix, int C, int accumulate,
                void* stream);

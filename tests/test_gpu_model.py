@@ -323,6 +323,59 @@ def test_commuted_concat_conv_matches_materialised_concat(mode):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_resize_last_order_of_the_commuted_concat_conv(mode):
+    """replica-sums mode CAN evaluate conv1x1(cat(a, bilinear_up(b))) as conv_a(a) first and ``y += bilinear_up(conv_b(b))`` last, with
+    the BatchNorm statistics of the sum taken by that streaming pass (ydl_resize_acc_sums; config.set_resize_last, off by default: it
+    measured no faster); the default order is: resize initialises y, conv_a accumulates with statistics.  Whole yolov5 model, both orders in sums mode: prediction, loss,
+    running statistics and every gradient agree (f32: to the atomics' arrival-order noise; bf16: one rounding of y moves)."""
+    import yolo_dual_amd as ydl
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd import config
+    ydl.set_compute_dtype(mode)
+    cfg = _cfg("yolov5_seg.yaml", {"C3_DCN": "C3"})
+    res = []
+    config.set_deterministic(False)                       # f32 too runs the replica-sums path then
+    try:
+        assert config.bn_sums(mode)
+        for on in (True, False):
+            config.set_resize_last(on)
+            m = ydl.YOLOv5Seg(cfg)
+            m.img_size = [128, 128]
+            sd = m.state_dict()
+            fill_state_dict(sd, 5)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            crit = ydl.SegmentationLoss(12, 0.0, CW, "dice", sync=False)
+            gen = torch.Generator("cuda").manual_seed(0)
+            x = torch.rand(4, 3, 128, 128, device="cuda", generator=gen)
+            t = torch.randint(0, 12, (4, 128, 128), device="cuda", generator=gen)
+            n0 = L.launch_count()
+            L.profile_begin()
+            out = m(x)
+            names = [r["name"] for r in L.profile_end()]
+            assert ("ydl_resize_acc_sums" in names) == on, names
+            total, _ = crit(out, t)
+            total.backward()
+            named = dict(m.named_parameters())
+            grads = {k: p.grad.detach().float().cpu().clone() for k, p in named.items() if getattr(p, "_ydl_touched", False)}
+            res.append((out.detach().cpu(), float(total), grads,
+                        {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if "running" in k}))
+    finally:
+        config.set_resize_last(False)
+        config.set_deterministic(None)
+        ydl.set_compute_dtype("bf16")
+    (o1, l1, g1, r1), (o0, l0, g0, r0) = res
+    assert sorted(g1) == sorted(g0)
+    # (bf16: the atomically added BN sums already move the early layers' gradients by 20 % between two runs of the SAME arm at this size)
+    to, tg = (2e-5, 5e-4) if mode == "f32" else (4e-2, 0.5)
+    assert l2_err(o1, o0) < to and abs(l1 - l0) <= to * abs(l0), (l2_err(o1, o0), l1, l0)
+    for k in r0:
+        assert l2_err(r1[k], r0[k]) < to, k
+    bad = {k: l2_err(g1[k], g0[k]) for k in g0 if l2_err(g1[k], g0[k]) >= tg}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("mode,c1,k,st,p", [("f32", 3, 6, 2, 2), ("bf16", 3, 6, 2, 2), ("f32", 1, 4, 2, 0), ("f32", 4, 4, 2, 2),
                                             ("f32", 3, 6, 3, 3)])
 def test_stem_space_to_depth_matches_plain_conv(mode, c1, k, st, p):

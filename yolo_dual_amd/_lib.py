@@ -75,6 +75,7 @@ SIGNATURES = {
     "ydl_maxpool_bwd": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ydl_resize_fwd": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "ydl_resize_bwd": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "ydl_resize_acc_sums": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp]),
     "ydl_copy2d": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
     "ydl_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ydl_nchw_to_s2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

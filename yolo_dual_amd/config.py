@@ -70,6 +70,21 @@ def set_commute_concat(on: bool) -> None:
     _STATE["commute_concat"] = bool(on)
 
 
+def resize_last() -> bool:
+    """commuted conv over a virtual concat in replica-sums (throughput) mode: the plain sub-convolutions first, the resized source
+    last through ydl_resize_acc_sums (read-modify-write + statistics in one streaming pass).  Off: the resized source initialises
+    the output and the last sub-convolution accumulates with statistics (the only order of the partial-row / parity mode)"""
+    # Default OFF — measured on MI355X, config 2, same-box A/B over 100 steps: 2362 / 2362 images/s with it against 2378 / 2372
+    # without.  The streaming pass takes 70-85 us per call (not the ~45 us its bytes would take: ~130 VALU instructions per 16-byte
+    # item — five unpacks, the bilinear blend, the statistics — make it instruction-bound), which is what the accumulate form of the
+    # point-wise kernel costs over the plain one; the order buys nothing and stays as a tested alternative.
+    return _STATE.setdefault("resize_last", os.environ.get("YDL_RESIZE_LAST", "0") != "0")
+
+
+def set_resize_last(on: bool) -> None:
+    _STATE["resize_last"] = bool(on)
+
+
 def stem_s2d() -> bool:
     """a stem conv on the raw region input whose k and p are multiples of its stride runs as the equivalent stride-1 conv
     over the space-to-depth converted input"""

@@ -3377,12 +3377,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 8 = patch-form kernel for the 3x3 / stride-1 layers (igemm2h_kernel): 1 (default) on, 0 ring kernel
 //              key 9 = fused-parity kernel for the k3 s2 p1 data gradients (igemm2s_kernel): 1 (default) on, 0 ring kernel
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
+//              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
 //              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
 // Process-wide and test-only: they change launch geometry, so callers that cache ydl_conv_fwd_grid_m/... must drop the cache
 // after a change (yolo_dual_amd._lib.debug_set does).
-extern int g_resize_int;       // spatial.hip
+extern int g_resize_int, g_resize_rows;       // spatial.hip
 extern "C" void ydl_debug_set(int key, int val) {
     if (key == 0) g_wgrad_tr = val;
     if (key == 1) g_pw_enabled = val;
@@ -3394,6 +3395,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 8) g_halo = val;
     if (key == 9) g_s2fused = val;
     if (key == 10) g_resize_int = val;
+    if (key == 11) g_resize_rows = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {

@@ -593,6 +593,28 @@ class Tape:
             if subs is None:
                 L.call(fwd_entry if ws_ptr is not None else "ydl_conv_fwd", gp, self.dt, _p(x.t), _p(w), _p(y.t), ws_ptr, 0, st)
                 return
+            if sums_mode and ws_ptr is not None and _cfg.resize_last() and sum(1 for e in subs if e[2]) == 1 and len(subs) >= 2:
+                # replica-sums mode: the plain sub-convolutions first (the first one overwrites y, no statistics), the resized
+                # source LAST through ydl_resize_acc_sums — a streaming read-modify-write that also adds the statistics of the sum.
+                # (The other order costs a full write of the resized tensor plus the point-wise kernel's register-layout
+                # read-modify-write with statistics: 42 + 94 us against 48 + ~45 us for the 128-channel 160^2 case of config 2.)
+                first = True
+                for (v, c0_, r_, gv) in subs:
+                    if r_:
+                        continue
+                    wv = ctypes.c_void_p(w.data_ptr() + c0_ * es)
+                    L.call("ydl_conv_fwd", ctypes.byref(gv), self.dt, _p(v.t), wv, _p(y.t), None, 0 if first else 1, st)
+                    first = False
+                for (v, c0_, r_, gv) in subs:
+                    if not r_:
+                        continue
+                    wv = ctypes.c_void_p(w.data_ptr() + c0_ * es)
+                    z = self.new(v.N, Cout, v.H, v.W)
+                    gz = L.ConvGeom(v.N, v.H, v.W, v.C, v.H, v.W, Cout, 1, 1, 0, v.ld, z.ld, Cin_p)
+                    L.call("ydl_conv_fwd", ctypes.byref(gz), self.dt, _p(v.t), wv, _p(z.t), None, 0, st)
+                    L.call("ydl_resize_acc_sums", self.dt, L.RESIZE_BILINEAR, _p(z.t), z.ld, _p(y.t), y.ld, v.N, v.H, v.W, Ho, Wo,
+                           Cout, 0.0, 0.0, ws_ptr, Cout_p, st)
+                return
             first = True
             for i, (v, c0_, r_, gv) in enumerate(subs):
                 wv = ctypes.c_void_p(w.data_ptr() + c0_ * es)
