@@ -202,6 +202,7 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
 
+    rstep = None
     if not args.eager:
         # Launch-mode selection (outside the timed region).  Three ways to issue the same kernels:
         #   eager   : ~330 entry-point calls per step from Python on two HIP streams (weight gradients + dead head branch overlap the
