@@ -137,6 +137,127 @@ __global__ __launch_bounds__(256) void dcnv3_kernel(const DcnArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------------
+// Backward for 3 x 3 kernels with >= 33 channels per group (a whole wavefront per (pixel, group) item, lane = channel), round 4.
+// The plain kernel above issues one f32 atomic wave-instruction per (point, bilinear corner): 36 per item and 64-channel pass, and the
+// op sits at the ~1.3 TB/s device-scope atomic rate.  With a whole wave on one item every sampling position is WAVE-UNIFORM, so the
+// corner gradients can be merged in registers first: a 5 x 5 window of dx cells anchored one cell up-left of the un-shifted top-left
+// tap (offsets below one pixel keep all 36 corners inside it) is a private float[25] per lane, indexed with a uniform index
+// (s_set_gpr_idx, no scratch, no LDS); at the end of the pass the touched cells go out with ONE atomic each — 16 for offsets near
+// zero, at most 25 — and corners that fall outside the window (large offsets) keep their direct atomic.  Same products as the plain
+// kernel, merged before instead of inside the memory system; grad_offset / grad_mask sums use DPP row adds + row broadcasts
+// (v_add_f32_dpp) instead of ds_bpermute butterflies.  Reference arithmetic: dcnv3_im2col_cuda.cuh:82-147.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_total(float v) {            // sum over the 64 lanes; the total is valid in lane 63
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));     // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));     // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xe, false));     // row_shr:4 (banks 1..3)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xc, false));     // row_shr:8 (banks 2..3)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));     // row_bcast:15 (rows 1, 3)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));     // row_bcast:31 (rows 2, 3)
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    constexpr int P = 9;
+    const int C = a.G * a.Gc;
+    const T* in = (const T*)a.in;
+    const T* off = (const T*)a.off;
+    const T* msk = (const T*)a.msk;
+    for (long long it = wave_id; it < a.items; it += nwaves) {
+        // (pixel, group) of this wave: uniform — say so, the window index below must be a scalar
+        const int g = __builtin_amdgcn_readfirstlane((int)(it % a.G));
+        const long long pix = it / a.G;
+        const int wo = __builtin_amdgcn_readfirstlane((int)(pix % a.Wo));
+        const long long t2 = pix / a.Wo;
+        const int ho = __builtin_amdgcn_readfirstlane((int)(t2 % a.Ho));
+        const int n = __builtin_amdgcn_readfirstlane((int)(t2 / a.Ho));
+        const int p0w = ((a.dw * 2) >> 1) - a.pw + wo * a.sw;
+        const int p0h = ((a.dh * 2) >> 1) - a.ph + ho * a.sh;
+        const float p0w_ = (float)p0w - (float)((a.dw * 2) >> 1) * a.scale;
+        const float p0h_ = (float)p0h - (float)((a.dh * 2) >> 1) * a.scale;
+        const int hb = (int)floorf(p0h_) - 1, wb = (int)floorf(p0w_) - 1;          // window anchor (cell (0, 0))
+        const T* offp = off + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2;
+        const T* mskp = msk + (size_t)pix * a.G * P + (size_t)g * P;
+        const T* imb = in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
+        float* gib = a.gin + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
+        for (int c0 = 0; c0 < a.Gc; c0 += 64) {
+            const int c = c0 + lane;
+            const bool act = c < a.Gc;
+            const float go = act ? ET<T>::ld((const T*)a.gout + (size_t)pix * C + g * a.Gc + c) : 0.f;
+            float win[25];
+#pragma unroll
+            for (int q = 0; q < 25; ++q) win[q] = 0.f;
+            unsigned touched = 0;                                   // uniform: bit q = cell q received a contribution
+            int k = 0;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j, ++k) {
+                    const float ow = ET<T>::ld(offp + 2 * k), oh = ET<T>::ld(offp + 2 * k + 1), mk = ET<T>::ld(mskp + k);
+                    const float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
+                    const float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
+                    float gmask = 0.f, goffw = 0.f, goffh = 0.f;
+                    if (lh_ > -1.f && lw_ > -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {          // (uniform)
+                        const int hl = __builtin_amdgcn_readfirstlane((int)floorf(lh_)), wl = __builtin_amdgcn_readfirstlane((int)floorf(lw_));
+                        const int hh_ = hl + 1, wh_ = wl + 1;
+                        const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        const bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wh_ <= a.W - 1;
+                        const bool b3 = hh_ <= a.H - 1 && wl >= 0, b4 = hh_ <= a.H - 1 && wh_ <= a.W - 1;
+                        const size_t o1 = ((size_t)hl * a.W + wl) * C + c, o2 = ((size_t)hl * a.W + wh_) * C + c;
+                        const size_t o3 = ((size_t)hh_ * a.W + wl) * C + c, o4 = ((size_t)hh_ * a.W + wh_) * C + c;
+                        const float v1 = (act && b1) ? ET<T>::ld(imb + o1) : 0.f;
+                        const float v2 = (act && b2) ? ET<T>::ld(imb + o2) : 0.f;
+                        const float v3 = (act && b3) ? ET<T>::ld(imb + o3) : 0.f;
+                        const float v4 = (act && b4) ? ET<T>::ld(imb + o4) : 0.f;
+                        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                        const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                        const float tg = go * mk;
+                        const int r = hl - hb, cc = wl - wb;                      // window cell of corner 1 (uniform)
+                        auto corner = [&](bool b, float w, int rr, int cq, size_t o) {
+                            if (b && w != 0.f) {                                  // a corner with bilinear weight 0 adds nothing
+                                if ((unsigned)rr < 5u && (unsigned)cq < 5u) {
+                                    const int q = rr * 5 + cq;
+                                    win[q] += w * tg;
+                                    touched |= 1u << q;
+                                } else if (act) {
+                                    atomicAdd(gib + o, w * tg);
+                                }
+                            }
+                        };
+                        corner(b1, w1, r, cc, o1);
+                        corner(b2, w2, r, cc + 1, o2);
+                        corner(b3, w3, r + 1, cc, o3);
+                        corner(b4, w4, r + 1, cc + 1, o4);
+                        const float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
+                        const float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
+                        gmask = go * val;
+                        goffw = a.scale * gww * tg;
+                        goffh = a.scale * ghw * tg;
+                    }
+                    gmask = wave_total(gmask);
+                    goffw = wave_total(goffw);
+                    goffh = wave_total(goffh);
+                    if (lane == 63) {
+                        float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + 2 * k;
+                        float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P + k;
+                        if (c0 == 0) { gof[0] = goffw; gof[1] = goffh; gmk[0] = gmask; }
+                        else { gof[0] += goffw; gof[1] += goffh; gmk[0] += gmask; }
+                    }
+                }
+            touched = __builtin_amdgcn_readfirstlane(touched);
+#pragma unroll
+            for (int q = 0; q < 25; ++q)
+                if ((touched >> q) & 1u) {                                       // (uniform) touched cells lie inside the image
+                    if (act) atomicAdd(gib + ((size_t)(hb + q / 5) * a.W + (wb + q % 5)) * C + c, win[q]);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Forward, vectorised: a lane owns one 16-byte channel chunk (8 bf16/f16 or 4 f32 channels) of a (pixel, group) item, so
 // a 64-lane load instruction moves 1 KiB of gathered rows instead of 128-256 bytes; the offsets and masks of the CTA's
 // DCN_PIX consecutive pixels are staged once, coalesced, in LDS as f32 (every lane of an item reads the same 3*P values).
@@ -294,6 +415,17 @@ extern "C" int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, c
     a.gin = grad_input; a.goff = grad_offset; a.gmsk = grad_mask;
     hipStream_t st = (hipStream_t)stream;
     YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16 || dtype == YDL_F16, "bad dtype");
+    static const int nowin = getenv("YDL_DCN_NOWIN") ? atoi(getenv("YDL_DCN_NOWIN")) : 0;
+    if (!nowin && kernel_h == 3 && kernel_w == 3 && a.seg == 64) {
+        // a whole wave per item: corner gradients merged in a register window before the atomics (dcnv3_bwd_win_kernel)
+        long long blocks = (a.items + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (dtype == YDL_F32) dcnv3_bwd_win_kernel<float><<<(int)blocks, 256, 0, st>>>(a);
+        else if (dtype == YDL_BF16) dcnv3_bwd_win_kernel<bf16_t><<<(int)blocks, 256, 0, st>>>(a);
+        else dcnv3_bwd_win_kernel<_Float16><<<(int)blocks, 256, 0, st>>>(a);
+        YDL_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == YDL_F32) dcnv3_kernel<float, true><<<dcn_grid(a), 256, 0, st>>>(a);
     else if (dtype == YDL_BF16) dcnv3_kernel<bf16_t, true><<<dcn_grid(a), 256, 0, st>>>(a);
     else dcnv3_kernel<_Float16, true><<<dcn_grid(a), 256, 0, st>>>(a);
