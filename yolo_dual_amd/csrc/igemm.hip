@@ -936,143 +936,6 @@ __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------------
-// igemm2q (round 4 experiment, YDL_RINGQ=1): the ring kernel with 32-deep K-steps.  A stage is (BM + BN) rows of 64 bytes = 16 KB for the
-// 128 x 128 tile, three stages are 48 KB: THREE CTAs share a CU (six waves per SIMD at <= 80 VGPRs: one fragment set, the other resident
-// waves cover the LDS latency instead of a software pipeline), where the 64-deep form fits two.  One DMA wave-instruction writes 16 rows
-// x 64 B; the 16-byte chunk swizzle for 64-byte rows is slot = chunk ^ (row & 4 ? 3 : 0): conflict-free for the hardware's
-// ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (four 64-byte rows make one 256-byte bank row; the four rows of a
-// residue class mod 4 that a lane group touches then land on four different slots).  K order: 32-channel block outer, tap inner.
-// Per K-step and wave: lgkmcnt(0) | vmcnt(2 (S-2)) + s_barrier | issue step k+S-1 | 6 fragment reads | 8 MFMAs.
-// ------------------------------------------------------------------------------------------------------
-#define QROWB 64
-template <int BM, int BN, int NW, int WP, int S>
-__global__ __launch_bounds__(NW * 64, 6) void igemm2q_kernel(const IgemmArgs p) {
-    using T = bf16_t;
-    constexpr int ES = 2;
-    constexpr int RPP = NW * 16;                // tile rows covered by one DMA pass of the CTA (one wave = 16 rows of 64 B)
-    static_assert(BM == RPP && BN == RPP, "one A row and one B row per thread and step");
-    constexpr int L = 2;                        // DMAs per thread per K-step
-    constexpr int WN = NW / WP;
-    constexpr int BNW = BN / WN;
-    constexpr int CT = BNW / 16;
-    constexpr int PT = BM / (16 * WP);
-    constexpr int STAGE = (BM + BN) * QROWB;
-    static_assert(S * STAGE >= BM * BN * 2 + 4096, "epilogue scratch");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* sTapA = (int*)(smem + S * STAGE);
-    int* sTapB = sTapA + MAXTAPS;
-    int* sTapD = sTapB + MAXTAPS;
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wc = wave % WN, wp = wave / WN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int mtile, ntile;
-    if (p.m_fastest) { ntile = tile / p.grid_m; mtile = tile - ntile * p.grid_m; }
-    else { mtile = tile / p.grid_n; ntile = tile - mtile * p.grid_n; }
-    int c_ntaps = p.ntaps, c_tap0 = 0, c_Hg = p.Hg, c_Wg = p.Wg, c_M = p.M, c_h0 = p.out_h0, c_w0 = p.out_w0;
-    if (p.ncls > 1) {
-        int c = 0;
-        while (c + 1 < p.ncls && mtile >= p.cls_tile0[c + 1]) ++c;
-        mtile -= p.cls_tile0[c];
-        c_ntaps = p.cls_ntaps[c]; c_tap0 = p.cls_tap0[c]; c_Hg = p.cls_Hg[c]; c_Wg = p.cls_Wg[c]; c_M = p.cls_M[c];
-        c_h0 = p.cls_h0[c]; c_w0 = p.cls_w0[c];
-    }
-    const int m0 = mtile * BM;
-    const int n0 = ntile * BN;
-    if (t < MAXTAPS) {
-        int da = 0, db = 0, dd = 0;
-        if (t < c_ntaps) {
-            da = ((int)p.dh[c_tap0 + t] * p.Wi + (int)p.dw[c_tap0 + t]) * p.lda * ES;
-            db = (int)p.wt[c_tap0 + t] * p.Kc * ES;
-            dd = ((int)p.dh[c_tap0 + t] & 0xffff) | ((int)p.dw[c_tap0 + t] << 16);
-        }
-        sTapA[t] = da; sTapB[t] = db; sTapD[t] = dd;
-    }
-    __syncthreads();
-    // this thread's DMA slot: row r, 16-byte slot qs; it fetches the logical chunk qs ^ swz(r)
-    const int r = t >> 2, qs = t & 3;
-    const unsigned q16 = (unsigned)((qs ^ ((r & 4) ? 3 : 0)) << 4);
-    unsigned rowoff = 0, vmask = 0;
-    {
-        int ih0 = -100000, iw0 = 0;
-        const int m = m0 + r;
-        if (m < c_M) {
-            const int gw = m % c_Wg;
-            const int tmp = m / c_Wg;
-            const int gh = tmp % c_Hg;
-            const int n = tmp / c_Hg;
-            ih0 = gh * p.in_mul;
-            iw0 = gw * p.in_mul;
-            rowoff = (unsigned)(((n * p.Hi + ih0) * p.Wi + iw0) * p.lda) * (unsigned)ES + q16;
-        }
-        for (int tp = 0; tp < c_ntaps; ++tp) {
-            const int dd = sTapD[tp];
-            const int dh = (int)(short)(dd & 0xffff), dw = dd >> 16;
-            const bool ok = (unsigned)(ih0 + dh) < (unsigned)p.Hi && (unsigned)(iw0 + dw) < (unsigned)p.Wi;
-            vmask |= ok ? (1u << tp) : 0u;
-        }
-    }
-    const unsigned browoff = (n0 + r) < p.Cout ? (unsigned)(n0 + r) * p.ldb_bytes + q16 : 0xF0000000u;
-    const int spt = p.Kc >> 5;                  // 32-channel blocks (Kc % 32 == 0)
-    const int nk = c_ntaps * spt;
-    u32x4 rsA, rsB;
-    {
-        const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
-        rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
-        rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xffffu, p.bytesB, 0x00020000u};
-    }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned wave_lds = lds0 + (unsigned)wave * (16 * QROWB);
-    int tap = 0, cb = 0;
-    int nxtA = sTapA[0], nxtB = sTapB[0];
-    auto issue_at = [&](unsigned stage_off) {
-        const int da = nxtA, db = nxtB;
-        const bool live = cb < spt;
-        const unsigned kb = (unsigned)cb << 6;                      // byte offset of the 32-channel block
-        const unsigned tbit = live ? 1u << tap : 0u;
-        const unsigned kbB = live ? kb : 0xF0000000u;
-        if (++tap == c_ntaps) { tap = 0; ++cb; }
-        nxtA = sTapA[tap];
-        nxtB = sTapB[tap];
-        const unsigned base = wave_lds + stage_off;
-        lds_dma16(rsA, base, (vmask & tbit) ? rowoff + (unsigned)da + kb : 0xFFFFFFFFu);
-        lds_dma16(rsB, base + BM * QROWB, browoff + (unsigned)db + kbB);
-    };
-    f32x4 acc[CT][PT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < S - 1; ++u) issue_at((unsigned)u * STAGE);
-    const int lrow = lane & 15;
-    const int lk = (((lane >> 4)) ^ ((lrow & 4) ? 3 : 0)) << 4;
-    const unsigned char* const fa = smem + BM * QROWB + (wc * BNW + lrow) * QROWB + lk;     // weights  (MFMA A operand)
-    const unsigned char* const fb = smem + (wp * (BM / WP) + lrow) * QROWB + lk;             // pixels   (MFMA B operand)
-    unsigned soff = 0, ioff = (unsigned)(S - 1) * STAGE;
-    for (int kk = 0; kk < nk; ++kk) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the previous step's fragments are in registers)
-        wait_vm_barrier<L * (S - 2)>();                             // step kk landed everywhere; everyone is done with step kk - 1
-        issue_at(ioff);                                             // step kk + S - 1 -> the stage step kk - 1 occupied
-        ioff = ioff + STAGE == S * STAGE ? 0u : ioff + STAGE;
-        uint4 af[CT], bfr[PT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(fa + soff + c * 16 * QROWB);
-#pragma unroll
-        for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(fb + soff + j * 16 * QROWB);
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
-        soff = soff + STAGE == S * STAGE ? 0u : soff + STAGE;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wait_vm_barrier<0>();              // the trailing all-zero DMAs must land before the epilogue reuses the LDS
-    igemm2_epilogue<BM, BN, NW, WP>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0);
-}
-
-// ------------------------------------------------------------------------------------------------------
 // igemm2p: the two-stage ring kernel as a PERSISTENT CTA that walks several output tiles, with the ring running across tile
 // boundaries.  In igemm2_kernel a tile costs t0 + n_k t1 with t0 (tap tables, row decode, the first DMA round trip, the epilogue's
 // LDS transpose, stores and statistics) as large as six K-steps; the step issued beyond a tile's last K-step was an all-zero dummy.
@@ -2397,29 +2260,6 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
     return 0;
 }
 
-template <int BM, int BN, int NW, int WP, int S>
-static int launch_igemm2q(IgemmArgs a, hipStream_t st, int fam) {
-    a.grid_n = (a.Cst + BN - 1) / BN;
-    int mtiles = (a.M + BM - 1) / BM;
-    if (a.ncls > 1) {
-        int acc = 0;
-        for (int c = 0; c < a.ncls; ++c) { a.cls_tile0[c] = acc; acc += (a.cls_M[c] + BM - 1) / BM; }
-        a.cls_tile0[a.ncls] = acc;
-        mtiles = acc;
-    }
-    a.grid_m = mtiles;
-    YDL_CHECK(a.bytesB < 0x08000000u, "ring kernel: weight matrix of 128 MiB or more is not supported");
-    const double wbytes = (double)a.Cout * a.Ttot * a.Kc * 2.0;
-    const double abytes = (double)a.N * a.Hi * a.Wi * a.lda * 2.0;
-    a.m_fastest = (wbytes > 2.0e6 && (double)mtiles * wbytes > (double)a.grid_n * abytes) ? 1 : 0;
-    const size_t smem = (size_t)S * (BM + BN) * QROWB + 3 * MAXTAPS * sizeof(int);
-    YDL_SET_MAX_LDS((igemm2q_kernel<BM, BN, NW, WP, S>), smem);
-    ydl_note_kernel(fam, "igemm2q_kernel<128,128,8,4,3>");
-    igemm2q_kernel<BM, BN, NW, WP, S><<<dim3(mtiles * a.grid_n), NW * 64, smem, st>>>(a);
-    YDL_LAUNCH_CHECK();
-    return 0;
-}
-
 // ring instantiations: id -> (BM, BN)
 static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128};
 static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64};
@@ -2530,8 +2370,6 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         if (hs == 2 || (hs == 0 && a.Kc == 64)) return launch_igemm2h<64, 2>(a, st, fam);
         return launch_igemm2h<64, 3>(a, st, fam);
     }
-    static const int ringq = getenv("YDL_RINGQ") ? atoi(getenv("YDL_RINGQ")) : 0;
-    if (ringq && id == 7 && (a.Kc & 31) == 0) return launch_igemm2q<128, 128, 8, 4, 3>(a, st, fam);
     switch (id) {
         case 1: return launch_igemm2<256, 128, 8, 4, 3>(a, st, fam);
         case 2: return launch_igemm2<128, 128, 4, 2, 4>(a, st, fam);
