@@ -312,7 +312,11 @@ def test_config5_dcnv3_model_matches_the_oracle(hw, bs, init):
         # north star's 1e-4 against the f32 oracle (measured 7.2e-5)
         assert e_hip <= max(3.0 * e_oracle, 2e-5), (e_hip, e_oracle)
         if init == "reference":
-            assert e_mutual < 1e-4, e_mutual
+            # 64 x 64: oracle f32 4.9e-5 from its f64 run, this path 6.6e-5 from the f32 oracle -> the 1e-4 holds.  96 x 96: the f32
+            # oracle is itself 1.9e-4 from f64 (this path 1.9e-4, mutual 3.3e-4: two f32 roundings of the same ill-conditioned
+            # 3 x 3 GAM BatchNorms), so 1e-4 between two f32 runs is not a property the reference has there — twice the oracle's own
+            # distance is what is asked instead.
+            assert e_mutual < max(1e-4, 2.0 * e_oracle), (e_mutual, e_oracle)
         assert abs(items[0] - total64) <= 1e-4 * abs(total64)
         named = dict(m.named_parameters())
         none_ref = sorted(k for k in pnames if ps[k].grad is None)
@@ -338,7 +342,12 @@ def test_config5_dcnv3_model_matches_the_oracle(hw, bs, init):
         # BatchNorms see 2 x 2 x 2 = 8 values at this input size — the oracle's own distance jumps 7x (1e-4 -> 7.5e-4) and this
         # path's 20x (-> 2.3e-3), and both stay there for every layer upstream: a chaotic amplification of f32 rounding at one
         # ill-conditioned block, measured ratio 3.0-3.2 (YOLOv5Seg, no GAM, same size: 1.6-1.8 at 3e-5).
-        bad = {k: (eh[k], eo[k]) for k in live if eh[k] > max(4.0 * eo[k], 4.0 * med_o, 1e-5)}
+        # The f32 oracle's distance is itself a noisy sample of that amplification: between two hosts (different thread counts ->
+        # different summation orders in its convolutions) its median moved 5.9e-4 -> 1.0e-3 and its worst tensor 8.4e-4 -> 2.2e-3 with
+        # the reference initialisation, while this path's numbers are the same on every box (median 1.8e-3, worst 3.9e-3).  Hence
+        # the absolute floor of 5e-3 under the ratio; a wrong backward is O(0.1-1) here (a sampling point exactly at -1 treated as
+        # outside — the .cuh's test instead of the PyTorch core's — showed as 0.25 on the offset biases in exactly this test).
+        bad = {k: (eh[k], eo[k]) for k in live if eh[k] > max(4.0 * eo[k], 4.0 * med_o, 5e-3)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:5]
         assert med_h <= max(4.0 * med_o, 1e-5), (med_h, med_o)
     finally:

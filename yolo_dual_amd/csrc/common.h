@@ -88,6 +88,18 @@ __device__ __forceinline__ void bn_dz_xhat_bf16x8(const uint4& yq, const uint4& 
     }
 }
 
+// Sum over the 64 lanes with DPP row shifts + row broadcasts (six v_add_f32_dpp, no LDS crossbar): the total is valid in LANE 63 ONLY.
+// The ds_bpermute butterfly of wave_sum below occupies the LDS for every step: the loss kernels reduce 39 values per wave with it and
+// spent half their time there (seg_loss_rep_fwd: 25 % LDS-active, 58 us; tools/sq_summary.py).
+__device__ __forceinline__ float wave_total63(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));     // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));     // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xe, false));     // row_shr:4 (banks 1..3)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xc, false));     // row_shr:8 (banks 2..3)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));     // row_bcast:15 (rows 1, 3)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));     // row_bcast:31 (rows 2, 3)
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -3,6 +3,10 @@
 // the decomposition is ours: a (pixel, group) item is owned by a power-of-two lane segment of one wavefront
 // (lanes = group channels, so every NHWC access is a contiguous run), and the grad_offset / grad_mask sums over the
 // channels are wavefront-shuffle butterflies instead of the reference's shared-memory trees.
+// One measure-zero case is decided by the oracle (functions/dcnv3_func.py:148-189, the pure-PyTorch core — the only form of the op
+// the reference can run without its missing binding): a sampling point EXACTLY at -1 is inside (">= -1"; the .cuh tests "> -1").
+// Its value is zero either way, but its offset gradient is the one-sided slope towards pixel 0, as grid_sample's backward gives —
+// with the module's own initialisation (offset weights zero, pad 1) every border tap sits exactly there.
 #include "common.h"
 #include <stdlib.h>
 
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void dcnv3_kernel(const DcnArgs a) {
                     float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
                     float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
                     float gmask = 0.f, goffw = 0.f, goffh = 0.f;
-                    if (lh_ > -1.f && lw_ > -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
+                    if (lh_ >= -1.f && lw_ >= -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
                         int hl = (int)floorf(lh_), wl = (int)floorf(lw_);
                         int hh_ = hl + 1, wh_ = wl + 1;
                         float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
@@ -147,16 +151,6 @@ __global__ __launch_bounds__(256) void dcnv3_kernel(const DcnArgs a) {
 // kernel, merged before instead of inside the memory system; grad_offset / grad_mask sums use DPP row adds + row broadcasts
 // (v_add_f32_dpp) instead of ds_bpermute butterflies.  Reference arithmetic: dcnv3_im2col_cuda.cuh:82-147.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_total(float v) {            // sum over the 64 lanes; the total is valid in lane 63
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));     // row_shr:1
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));     // row_shr:2
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xe, false));     // row_shr:4 (banks 1..3)
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xc, false));     // row_shr:8 (banks 2..3)
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));     // row_bcast:15 (rows 1, 3)
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));     // row_bcast:31 (rows 2, 3)
-    return v;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
     const int lane = threadIdx.x & 63;
@@ -199,7 +193,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
                     const float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
                     const float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
                     float gmask = 0.f, goffw = 0.f, goffh = 0.f;
-                    if (lh_ > -1.f && lw_ > -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {          // (uniform)
+                    if (lh_ >= -1.f && lw_ >= -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {          // (uniform)
                         const int hl = __builtin_amdgcn_readfirstlane((int)floorf(lh_)), wl = __builtin_amdgcn_readfirstlane((int)floorf(lw_));
                         const int hh_ = hl + 1, wh_ = wl + 1;
                         const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
@@ -237,9 +231,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
                         goffw = a.scale * gww * tg;
                         goffh = a.scale * ghw * tg;
                     }
-                    gmask = wave_total(gmask);
-                    goffw = wave_total(goffw);
-                    goffh = wave_total(goffh);
+                    gmask = wave_total63(gmask);
+                    goffw = wave_total63(goffw);
+                    goffh = wave_total63(goffh);
                     if (lane == 63) {
                         float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + 2 * k;
                         float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P + k;
@@ -317,7 +311,7 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_vec_kernel(const DcnArgs a) {
                         const float ow = offp[2 * k], oh = offp[2 * k + 1], mk = mskp[k];
                         const float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
                         const float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
-                        if (act && lh_ > -1.f && lw_ > -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
+                        if (act && lh_ >= -1.f && lw_ >= -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
                             const int hl = (int)floorf(lh_), wl = (int)floorf(lw_);
                             const int hh_ = hl + 1, wh_ = wl + 1;
                             const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;

@@ -231,12 +231,12 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
 #pragma unroll
     for (int c = 0; c < MC; ++c)
         if (c < C) {
-            float a = wave_sum(accI[c]), b = wave_sum(accP[c]), d = wave_sum(accT[c]);
-            if (lane == 0) { red[wave][c] = a; red[wave][MC + c] = b; red[wave][2 * MC + c] = d; }
+            float a = wave_total63(accI[c]), b = wave_total63(accP[c]), d = wave_total63(accT[c]);      // (DPP: totals in lane 63)
+            if (lane == 63) { red[wave][c] = a; red[wave][MC + c] = b; red[wave][2 * MC + c] = d; }
         }
     {
-        float a = wave_sum(ce_num), b = wave_sum(ce_den), d = wave_sum(sm_num);
-        if (lane == 0) { red[wave][3 * MC] = a; red[wave][3 * MC + 1] = b; red[wave][3 * MC + 2] = d; }
+        float a = wave_total63(ce_num), b = wave_total63(ce_den), d = wave_total63(sm_num);
+        if (lane == 63) { red[wave][3 * MC] = a; red[wave][3 * MC + 1] = b; red[wave][3 * MC + 2] = d; }
     }
     __syncthreads();
     float* dst = part + ((size_t)n * gridDim.x + blockIdx.x) * (3 * C + 3);
@@ -515,12 +515,12 @@ __global__ __launch_bounds__(256) void seg_loss_rep_fwd_kernel(const float* __re
 #pragma unroll
     for (int c = 0; c < MC; ++c)
         if (c < C) {
-            float a = wave_sum(accI[c]), b = wave_sum(accP[c]), d = wave_sum(accT[c]);
-            if (lane == 0) { red[wave][c] = a; red[wave][MC + c] = b; red[wave][2 * MC + c] = d; }
+            float a = wave_total63(accI[c]), b = wave_total63(accP[c]), d = wave_total63(accT[c]);      // (DPP: totals in lane 63)
+            if (lane == 63) { red[wave][c] = a; red[wave][MC + c] = b; red[wave][2 * MC + c] = d; }
         }
     {
-        float a = wave_sum(ce_num), b = wave_sum(ce_den), d = wave_sum(sm_num);
-        if (lane == 0) { red[wave][3 * MC] = a; red[wave][3 * MC + 1] = b; red[wave][3 * MC + 2] = d; }
+        float a = wave_total63(ce_num), b = wave_total63(ce_den), d = wave_total63(sm_num);
+        if (lane == 63) { red[wave][3 * MC] = a; red[wave][3 * MC + 1] = b; red[wave][3 * MC + 2] = d; }
     }
     __syncthreads();
     float* dst = part + ((size_t)n * gridDim.x + blockIdx.x) * (3 * C + 3);
