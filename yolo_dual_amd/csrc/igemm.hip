@@ -72,6 +72,7 @@ template <> struct Mma<float> {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // XCD-aware work-item order (speed only, any placement is correct): the dispatcher deals consecutive workgroups
 // round-robin over the 8 XCDs, each with a private L2.  Remapping linear id L -> (L % 8) * chunk + L / 8 hands every XCD
@@ -1688,11 +1689,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void igemm2s_kernel(const IgemmArg
 struct PwArgs {
     const void* X; const void* W; void* Y; float* stats;
     int M, lda, ldc, Cout, WN, accumulate, block_m, stats_ld, stats_atomic;
-    unsigned bytesX, ldw_bytes;
+    unsigned bytesX, ldw_bytes, bytesY;
     int tstore;          // 1: stores go through a per-wave LDS transpose (16 bytes per lane, whole pixel rows per instruction)
 };
 
-template <typename T, int RB, int CT, int NW, bool TS>
+template <typename T, int RB, int CT, int NW, bool TS, bool ACC = false, bool STATS = true>
 __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     constexpr int ES = sizeof(T);
     constexpr int J = RB / 64;                  // fragment groups per K row (each = 4 lane-group chunks of 16 B)
@@ -1705,7 +1706,9 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;                                      // [Cout][RB], chunk q of row r at slot q ^ sw(r)
     float* sred = (float*)(smem + (size_t)p.Cout * RB);            // [WP][Cout][2] (mean, M2) + [WP] counts
-    unsigned char* const stage = smem + (((size_t)p.Cout * RB + (size_t)(NW / p.WN) * p.Cout * 2 * sizeof(float) + 64 + 15) & ~(size_t)15);
+    unsigned char* const stage = smem + (size_t)p.Cout * RB;       // TS: per-wave transposed store tiles, the SAME bytes (dead after the
+                                                                   // main loop; a barrier separates the two uses) — 256 x 256 weights
+                                                                   // (128 KB) + 32 KB of tiles is exactly the CU's 160 KB
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int WN = p.WN, WP = NW / WN;
     const int wc = wave % WN, wp = wave / WN;
@@ -1728,17 +1731,27 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
             b[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-#pragma unroll
-    for (int u = 0; u < NB; ++u)
-        if (u < nsteps) load(u, bq[u]);
-
-    for (int i = t; i < p.Cout * CPR; i += NW * 64) {
-        const int r = i / CPR, q = i & (CPR - 1);
-        const uint4 v = *(const uint4*)((const unsigned char*)p.W + (size_t)r * p.ldw_bytes + (q << 4));
-        const int sw = CPR == 8 ? (r >> 1) & 7 : r & 15;
-        *(uint4*)(sW + r * RB + ((q ^ sw) << 4)) = v;
+    // The weights go FIRST and by LDS-DMA (a wave instruction = 1 KiB of the image = 1024 / RB rows; the lane at slot s of row r
+    // fetches the logical chunk s ^ sw(r): the swizzle moves to the source address), the first NB activation tiles behind them.
+    // Memory operations return in order: issued the other way round (round 3) the weights queued behind NB x J x 1 KiB per wave
+    // — 192 KB per CU, HALF of a 256 -> 256 @ 80^2 layer's input chip-wide — and the first MFMA waited for all of it: load,
+    // multiply and store phases ran one after the other.
+    {
+        const unsigned long long pwg = (unsigned long long)p.W;
+        const u32x4 rsW = u32x4{(unsigned)pwg, (unsigned)(pwg >> 32) & 0xffffu, (unsigned)p.Cout * p.ldw_bytes, 0x00020000u};
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        constexpr int RPI = 1024 / RB;                        // rows per DMA instruction
+        const int ninstr = (p.Cout * RB) >> 10;
+        for (int k = uw; k < ninstr; k += NW) {
+            const int r = k * RPI + lane / CPR, sl = lane & (CPR - 1);
+            const int sw = CPR == 8 ? (r >> 1) & 7 : r & 15;
+            lds_dma16(rsW, lds0 + (unsigned)k * 1024u, (unsigned)r * p.ldw_bytes + (unsigned)((sl ^ sw) << 4));
+        }
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NB; ++u) load(u, bq[u]);                    // (tiles beyond the range are out-of-range offsets: zeros, no traffic)
+    wait_vm_barrier<NB * J>();                                      // own DMAs landed (only the NB * J younger loads may be outstanding), then everyone's
 
     const int co0 = wc * CT * 16;
     const unsigned char* const wbase = sW + (co0 + lrow) * RB;
@@ -1748,8 +1761,93 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) { s1[v] = 0.f; s2[v] = 0.f; }
     float cnt = 0.f;
-    const bool want_stats = p.stats != nullptr;
+    const bool want_stats = STATS && p.stats != nullptr;      // (STATS = false: the input-gradient launches — 2 x CT x 4 registers less)
 
+    // Steady loop of the non-accumulating launches: NO control flow and no exec-masked memory operation.  gfx950 counts loads and
+    // stores in one in-order counter (vmcnt); behind a conditional prefetch (`if (i + NB < nsteps) load`) or an exec-masked store the
+    // compiler no longer knows how many operations are outstanding, assumes the fewest and waits with vmcnt(7..0) for a tile's
+    // loads — which also waits for every YOUNGER-but-one prefetch: the NB tiles "in flight" were one (tools/asm_loops.py; round 4).
+    // Here every wave runs a multiple of NB steps, tiles beyond its range are out-of-range buffer offsets (loads return zeros,
+    // stores are dropped, neither moves data), and the waits come out as vmcnt(NB * J + ...) as intended.
+    if constexpr (!ACC) {
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.Y, 0, p.bytesY, 0x00020000);
+        auto step = [&](int i, uint4 (&b)[J], bool prefetch) {
+            asm volatile("" ::: "memory");             // (weight fragments re-read from LDS every step, as below)
+            f32x4 acc[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int koff = (((j << 2) | lgrp) ^ swr) << 4;
+                uint4 af[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(wbase + c * 16 * RB + koff);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) Mma<T>::run(af[c], b[j], acc[c]);
+            }
+            if (prefetch) load(i + NB, b);
+            const int tile_m = m_begin + ((i * WP + wp) << 4);
+            if constexpr (TS) {
+                constexpr int NCH = CT * 16 * ES / 16;          // 16-byte chunks per tile row
+                constexpr int RPP = 64 / NCH;                   // rows per store instruction
+                unsigned char* tb = stage + wave * (16 * NCH * 16);
+                const int swm = (NCH - 1) & 15;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if constexpr (sizeof(T) == 4) {
+                        const int ch = c * 4 + lgrp;
+                        *(float4*)(tb + lrow * (NCH * 16) + ((ch ^ (lrow & swm)) << 4)) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+                    } else {
+                        const int ch = c * 2 + (lgrp >> 1);
+                        uint2 w2;
+                        w2.x = (uint32_t)f2bf(acc[c][0]) | ((uint32_t)f2bf(acc[c][1]) << 16);
+                        w2.y = (uint32_t)f2bf(acc[c][2]) | ((uint32_t)f2bf(acc[c][3]) << 16);
+                        *(uint2*)(tb + lrow * (NCH * 16) + ((ch ^ (lrow & swm)) << 4) + ((lgrp & 1) << 3)) = w2;
+                    }
+                }
+#pragma unroll
+                for (int ps = 0; ps < 16 / RPP; ++ps) {
+                    const int row = ps * RPP + lane / NCH, ch = lane % NCH;
+                    const uint4 v4 = *(const uint4*)(tb + row * (NCH * 16) + ((ch ^ (row & swm)) << 4));
+                    const unsigned off = ((unsigned)(tile_m + row) * (unsigned)p.ldc + (unsigned)co0) * ES + (unsigned)(ch << 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{v4.x, v4.y, v4.z, v4.w}, rsY, tile_m + row < m_end ? off : 0xFFFFFFFFu, 0, 0);
+                }
+            } else {
+                const int m = tile_m + lrow;
+                const unsigned off = m < m_end ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(co0 + lgrp * 4)) * ES : 0xFFFFFFFFu;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if constexpr (sizeof(T) == 4) {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[c][0]), __float_as_uint(acc[c][1]), __float_as_uint(acc[c][2]),
+                                                                     __float_as_uint(acc[c][3])}, rsY, off, c * 16 * ES, 0);
+                    } else {
+                        u32x2 w2;
+                        w2.x = (uint32_t)f2bf(acc[c][0]) | ((uint32_t)f2bf(acc[c][1]) << 16);
+                        w2.y = (uint32_t)f2bf(acc[c][2]) | ((uint32_t)f2bf(acc[c][3]) << 16);
+                        __builtin_amdgcn_raw_buffer_store_b64(w2, rsY, off, c * 16 * ES, 0);
+                    }
+                }
+            }
+            if (want_stats) {                           // (rows beyond the range are zeros: they add nothing to the sums)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[c * 4 + e] += acc[c][e];
+                        s2[c * 4 + e] = fmaf(acc[c][e], acc[c][e], s2[c * 4 + e]);
+                    }
+                cnt += (tile_m + lrow < m_end) ? 1.f : 0.f;
+            }
+        };
+        const int nfull = nsteps / NB * NB;
+        for (int i0 = 0; i0 < nfull; i0 += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) step(i0 + u, bq[u], true);
+        }
+#pragma unroll
+        for (int u = 0; u < NB - 1; ++u)                    // the last nsteps % NB tiles (their loads were issued above; nothing follows them)
+            if (nfull + u < nsteps) step(nfull + u, bq[u], false);
+    } else
     for (int i0 = 0; i0 < nsteps; i0 += NB) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -1857,6 +1955,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     }
 
     if (want_stats) {
+        if constexpr (TS) __syncthreads();                   // every wave is done with its store tiles: sred takes their place
         // per-lane (count, mean, M2), then Chan-merge over the 16 pixel lanes: stage s pairs lanes that differ in bit s;
         // the lane whose bit is 0 keeps the even-indexed aggregates, its partner the odd ones (live values halve).
         float mean[NV], m2[NV];
@@ -2116,16 +2215,14 @@ static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) 
     pl.block_m = bm;
     pl.grid_m = (M + bm - 1) / bm;
     const int WP = pl.NW / pl.WN;
-    pl.smem = (((size_t)wbytes + (size_t)WP * Cout * 2 * sizeof(float) + 64 + 15) & ~(size_t)15);
-    pl.tstage = (size_t)pl.NW * 16 * (pl.CT * 16 * es);      // per-wave transposed store tiles
+    pl.smem = (((size_t)wbytes + (size_t)WP * Cout * 2 * sizeof(float) + 64 + 15) & ~(size_t)15);      // direct stores: weights + reduction scratch
+    pl.tstage = (size_t)pl.NW * 16 * (pl.CT * 16 * es);      // per-wave transposed store tiles (the reduction scratch aliases them)
     pl.ok = true;
     return pl;
 }
 
 template <typename T, int RB, int CT, int NW>
 static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int fam) {
-    YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, true>), 160 * 1024);
-    YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, false>), 160 * 1024);
     PwArgs a2 = a;
     static const int no_t = getenv("YDL_PW_NOTSTORE") ? atoi(getenv("YDL_PW_NOTSTORE")) : 0;
     // (bf16 only: the f32 instantiations lose an occupancy step or spill with the extra staging code; parity mode keeps direct stores)
@@ -2135,7 +2232,11 @@ static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int 
     // measured per layer (tools/conv_bench.py dgrad --acc 1): faster everywhere (-8 ... -27 %) but on 256-byte K rows with 128-channel
     // wave tiles, where the direct read-modify-write wins (128->128 @160^2: 90 vs 111 us)
     const bool acc_ok = a.stats == nullptr && acc_ts && !(RB == 256 && CT == 8);
-    a2.tstore = (sizeof(T) == 2 && (!a.accumulate || acc_ok) && !no_t && pl.smem + pl.tstage <= 158 * 1024) ? 1 : 0;
+    const size_t wbytes = (size_t)a.Cout * RB;
+    const size_t ts_smem = wbytes + (pl.tstage > pl.smem - wbytes ? pl.tstage : pl.smem - wbytes);
+    // (512-byte rows x 128-channel waves: the transposed stores fit the register file only without the statistics' 64 registers)
+    const bool ts_regs = !(RB == 512 && CT == 8 && a.stats != nullptr);
+    a2.tstore = (sizeof(T) == 2 && (!a.accumulate || acc_ok) && !no_t && ts_regs && ts_smem <= 160 * 1024) ? 1 : 0;
     {
         // the store path is part of the recorded name: "ts" = per-wave LDS-transposed 16-byte stores, "direct" = register-layout stores
         static const std::string base = std::string("pw_kernel<") + (sizeof(T) == 4 ? "f32" : "bf16") + "," + std::to_string(RB) + "," +
@@ -2143,8 +2244,25 @@ static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int 
         static const std::string nm_ts = base + ",ts>", nm_direct = base + ",direct>";
         ydl_note_kernel(fam, (a2.tstore ? nm_ts : nm_direct).c_str());
     }
-    if (a2.tstore) pw_kernel<T, RB, CT, NW, true><<<pl.grid_m, NW * 64, pl.smem + pl.tstage, st>>>(a2);
-    else pw_kernel<T, RB, CT, NW, false><<<pl.grid_m, NW * 64, pl.smem, st>>>(a2);
+    {
+        const unsigned long long by = ((unsigned long long)(a.M - 1) * (unsigned long long)a.ldc + (unsigned long long)a.Cout) * sizeof(T);
+        YDL_CHECK(by < 0xFFFFFFFFull, "point-wise output beyond the 4 GiB a buffer descriptor addresses");
+        a2.bytesY = (unsigned)by;
+    }
+    const size_t sm = a2.tstore ? ts_smem : pl.smem;
+#define PW_LAUNCH(TS_, ACC_, ST_)                                                     \
+    do {                                                                              \
+        YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, TS_, ACC_, ST_>), 160 * 1024);      \
+        pw_kernel<T, RB, CT, NW, TS_, ACC_, ST_><<<pl.grid_m, NW * 64, sm, st>>>(a2); \
+    } while (0)
+    if (a2.accumulate) {
+        if (a2.tstore) PW_LAUNCH(true, true, true); else PW_LAUNCH(false, true, true);
+    } else if (a2.stats) {
+        if (a2.tstore) PW_LAUNCH(true, false, true); else PW_LAUNCH(false, false, true);
+    } else {
+        if (a2.tstore) PW_LAUNCH(true, false, false); else PW_LAUNCH(false, false, false);
+    }
+#undef PW_LAUNCH
     YDL_LAUNCH_CHECK();
     return 0;
 }
