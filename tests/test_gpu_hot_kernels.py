@@ -151,8 +151,9 @@ PW = [
     ("pw_rb512_bf16", "bf16", 4, 256, 64, "pw_kernel<bf16,512,4,4,ts>"),
     # 256 -> 128: 512-byte rows on 64-channel waves
     ("pw_rb512_c128_bf16", "bf16", 4, 256, 128, "pw_kernel<bf16,512,4,4,ts>"),
-    # 256 -> 256: the 8-wave instantiation (direct stores)
-    ("pw_rb512_nw8_bf16", "bf16", 4, 256, 256, "pw_kernel<bf16,512,8,8,direct>"),
+    # 256 -> 256: the 8-wave instantiation (transposed stores since round 4: the reduction scratch aliases the store tiles, 128 KB of
+    # weights + 32 KB of tiles = the CU's 160 KB; two pixel tiles in flight instead of three pay for the statistics' registers)
+    ("pw_rb512_nw8_bf16", "bf16", 4, 256, 256, "pw_kernel<bf16,512,8,8,ts>"),
 ]
 
 

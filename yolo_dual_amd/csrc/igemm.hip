@@ -1701,7 +1701,11 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #ifndef PW_NB_SHORT
 #define PW_NB_SHORT 4
 #endif
-    constexpr int NB = (J >= 8) ? 3 : PW_NB_SHORT;        // pixel tiles in flight per wave (register budget)
+#ifndef PW_NB_TS8
+#define PW_NB_TS8 2
+#endif
+    // pixel tiles in flight per wave (register budget; 512-byte rows x 128-channel waves with statistics AND transposed stores: one less)
+    constexpr int NB = (J >= 8) ? ((TS && STATS && CT == 8 && !ACC) ? PW_NB_TS8 : 3) : PW_NB_SHORT;
     constexpr int NV = CT * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;                                      // [Cout][RB], chunk q of row r at slot q ^ sw(r)
@@ -2235,7 +2239,10 @@ static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int 
     const size_t wbytes = (size_t)a.Cout * RB;
     const size_t ts_smem = wbytes + (pl.tstage > pl.smem - wbytes ? pl.tstage : pl.smem - wbytes);
     // (512-byte rows x 128-channel waves: the transposed stores fit the register file only without the statistics' 64 registers)
-    const bool ts_regs = !(RB == 512 && CT == 8 && a.stats != nullptr);
+#ifndef PW_TS8_STATS
+#define PW_TS8_STATS 1
+#endif
+    const bool ts_regs = PW_TS8_STATS || !(RB == 512 && CT == 8 && a.stats != nullptr);
     a2.tstore = (sizeof(T) == 2 && (!a.accumulate || acc_ok) && !no_t && ts_regs && ts_smem <= 160 * 1024) ? 1 : 0;
     {
         // the store path is part of the recorded name: "ts" = per-wave LDS-transposed 16-byte stores, "direct" = register-layout stores
