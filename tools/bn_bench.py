@@ -51,3 +51,17 @@ for npix, C, rows in SHAPES:
     mb = npix * C * 2 / 1e6
     print(f"npix {npix:7d} C {C:5d} rows {rows:5d} | finalize {t_fin:6.1f}us | act_fwd {t_fwd:6.1f}us {2 * mb / t_fwd / 1e3:5.2f}TB/s"
           f" | act_bwd {t_bwd:6.1f}us {5 * mb / t_bwd / 1e3:5.2f}TB/s", flush=True)
+
+# throughput-mode forward on replica sums (ydl_bn_act_fwd_sums): the kernel of the training step
+print("--- ydl_bn_act_fwd_sums (SiLU, no residual)")
+for npix, C, rows in SHAPES:
+    y = torch.randn(npix, C, device=dev).bfloat16()
+    out = torch.empty_like(y)
+    sums = torch.zeros(16, C, device=dev)
+    sums[0] = 0.1 * npix; sums[1] = 1.5 * npix
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    mean, invstd, scale, shift = (torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev))
+    t = timeit(lambda: L.call("ydl_bn_act_fwd_sums", L.YDL_BF16, P(y), C, P(sums), C, npix, P(g), P(b), 1e-5, 0.03, None, None, P(mean), P(invstd),
+                              P(scale), P(shift), 1, None, 0, 0, 1, P(out), C, npix, C, C, st))
+    mb = npix * C * 2 / 1e6
+    print(f"npix {npix:7d} C {C:5d} | act_fwd_sums {t:6.1f}us {2 * mb / t:5.2f}TB/s", flush=True)
