@@ -49,8 +49,8 @@ for npix, C, rows in SHAPES:
     t_bwd = timeit(lambda: L.call("ydl_bn_act_bwd", L.YDL_BF16, P(y), C, P(dout), C, P(out), C, P(g), P(mean), P(invstd), P(scale), P(shift),
                                   0, 1, P(dy), C, None, 0, P(dg), P(db), 1, P(ws2), npix, C, C, st))
     mb = npix * C * 2 / 1e6
-    print(f"npix {npix:7d} C {C:5d} rows {rows:5d} | finalize {t_fin:6.1f}us | act_fwd {t_fwd:6.1f}us {2 * mb / t_fwd / 1e3:5.2f}TB/s"
-          f" | act_bwd {t_bwd:6.1f}us {5 * mb / t_bwd / 1e3:5.2f}TB/s", flush=True)
+    print(f"npix {npix:7d} C {C:5d} rows {rows:5d} | finalize {t_fin:6.1f}us | act_fwd {t_fwd:6.1f}us {2 * mb / t_fwd:5.2f}TB/s"
+          f" | act_bwd {t_bwd:6.1f}us {5 * mb / t_bwd:5.2f}TB/s", flush=True)
 
 # throughput-mode forward on replica sums (ydl_bn_act_fwd_sums): the kernel of the training step
 print("--- ydl_bn_act_fwd_sums (SiLU, no residual)")
