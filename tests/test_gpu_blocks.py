@@ -423,6 +423,36 @@ def test_sgd_ema_flat_optimizer():
     ydl.set_compute_dtype("bf16")
 
 
+def test_multi_run_optimizer_launch_equals_the_per_run_launches():
+    """ydl_sgd_ema_step_multi (one launch, float4 groups aligned to the arena, element form at the run ends) against
+    ydl_sgd_ema_step_dev run by run, bit for bit — runs at offsets that are not multiples of four, of lengths 1..5 and large,
+    with and without weight decay / first-step / EMA-only rows"""
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd.tape import _p, _stream
+    n_tot = 70001
+    gen = torch.Generator("cuda").manual_seed(3)
+    base = [torch.randn(n_tot, device="cuda", generator=gen) for _ in range(4)]
+    hyper = torch.tensor([0.01, 0.02, 0.03, 0.9, 5e-4, 0.5, 0.999], device="cuda")
+    # (offset, n_decay, n_params, n_total, lr index, flags)
+    rows = [(0, 3, 3, 3, 0, 1), (3, 0, 5, 5, 1, 0), (8, 0, 0, 1, 0, 0), (9, 30001, 30001, 30001, 0, 1 | 2), (30010, 0, 20002, 20002, 2, 0),
+            (50012, 0, 0, 19989, 0, 0)]
+    assert rows[-1][0] + rows[-1][3] == n_tot
+    tab = torch.tensor(rows, dtype=torch.int64).cuda()
+    st = _stream()
+    for use_ema in (1, 0):
+        pa, ga, ma, ea = [t.clone() for t in base]
+        L.call("ydl_sgd_ema_step_multi", _p(pa), _p(ga), _p(ma), _p(ea) if use_ema else None, _p(tab), len(rows), max(r[3] for r in rows),
+               _p(hyper), use_ema, st)
+        pb, gb, mb, eb = [t.clone() for t in base]
+        for off, nd, npar, n, gi, fl in rows:
+            if npar == 0 and not use_ema:
+                continue
+            L.call("ydl_sgd_ema_step_dev", _p(pb[off:]), _p(gb[off:]), _p(mb[off:]), _p(eb[off:]) if use_ema else None, nd, npar, n, _p(hyper), gi,
+                   fl & 1, (fl >> 1) & 1, use_ema, st)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ea, eb) and torch.equal(ga, gb)
+
+
 def test_miou_confusion():
     from yolo_dual_amd.evaluate import ConfusionMatrix
     g = Golden("miou")

@@ -273,6 +273,20 @@ __global__ __launch_bounds__(256) void sgd_ema_dev_kernel(float* __restrict__ pa
 // All runs of one optimizer step in ONE launch: grid row y handles run y = {offset, n_decay, n_params, n_total, lr_index,
 // flags (bit 0 weight decay, bit 1 first step)} of the device table (the per-run launches of the dead / live / BN / bias / buffer
 // ranges cost ~7 us each, nine of them per step on BASELINE config 2).  Same arithmetic as sgd_ema_dev_kernel.
+__device__ __forceinline__ void sgd_ema_elem(float& p, float g, float& b, float& e, bool is_param, bool dec, bool first, bool use_ema,
+                                             float lr, float mom, float wd, float gscale, float d) {
+    if (is_param) {
+        g = g * gscale;
+        if (dec && wd != 0.f) g = g + wd * p;
+        b = first ? g : mom * b + g;
+        const float upd = g + mom * b;
+        p = p - lr * upd;
+    }
+    if (use_ema) {
+        e = e * d;
+        e = e + (1.f - d) * p;
+    }
+}
 __global__ __launch_bounds__(256) void sgd_ema_multi_kernel(float* __restrict__ params, const float* __restrict__ grads,
                                                             float* __restrict__ mombuf, float* __restrict__ ema,
                                                             const long long* __restrict__ runs, const float* __restrict__ hyper,
@@ -280,25 +294,38 @@ __global__ __launch_bounds__(256) void sgd_ema_multi_kernel(float* __restrict__ 
     const long long* r = runs + (size_t)blockIdx.y * 6;
     const long long off = r[0], n_decay = r[1], n_params = r[2], n_total = r[3];
     const int lr_idx = (int)r[4], flags = (int)r[5];
-    const int first = (flags >> 1) & 1;
+    const bool first = (flags >> 1) & 1;
     const float lr = hyper[lr_idx], mom = hyper[3], wd = (flags & 1) ? hyper[4] : 0.f, gscale = hyper[5], d = hyper[6];
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += (long long)gridDim.x * blockDim.x) {
-        float p = params[off + i];
-        if (i < n_params) {
-            bool dec = i < n_decay;
-            float g = grads[off + i] * gscale;
-            if (dec && wd != 0.f) g = g + wd * p;
-            float b = first ? g : mom * mombuf[off + i] + g;
-            mombuf[off + i] = b;
-            float upd = g + mom * b;
-            p = p - lr * upd;
-            params[off + i] = p;
-        }
-        if (use_ema && ema != nullptr) {
-            float e = ema[off + i];
-            e = e * d;
-            e = e + (1.f - d) * p;
-            ema[off + i] = e;
+    const bool ue = use_ema && ema != nullptr;
+    // 16 bytes per lane and stream (seven streams: p rw, g r, momentum rw, ema rw): the run is walked in float4 groups aligned to the
+    // ARENA (so every access is 16-byte aligned whatever the run's offset); the groups that straddle the run's ends, and runs whose
+    // decay / parameter boundary is not the whole run, take the element form.  Same arithmetic per element either way.
+    const long long a0 = off & ~3ll, end = off + n_total;
+    const bool uniform = (n_params == n_total || n_params == 0) && (n_decay == n_params || n_decay == 0);
+    for (long long q = a0 + 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x); q < end; q += 4ll * gridDim.x * blockDim.x) {
+        if (uniform && q >= off && q + 4 <= end) {
+            const bool isp = n_params != 0, dec = n_decay != 0;
+            float4 p4 = *(const float4*)(params + q), g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4, e4 = g4;
+            if (isp) { g4 = *(const float4*)(grads + q); if (!first) b4 = *(const float4*)(mombuf + q); }
+            if (ue) e4 = *(const float4*)(ema + q);
+            sgd_ema_elem(p4.x, g4.x, b4.x, e4.x, isp, dec, first, ue, lr, mom, wd, gscale, d);
+            sgd_ema_elem(p4.y, g4.y, b4.y, e4.y, isp, dec, first, ue, lr, mom, wd, gscale, d);
+            sgd_ema_elem(p4.z, g4.z, b4.z, e4.z, isp, dec, first, ue, lr, mom, wd, gscale, d);
+            sgd_ema_elem(p4.w, g4.w, b4.w, e4.w, isp, dec, first, ue, lr, mom, wd, gscale, d);
+            if (isp) { *(float4*)(params + q) = p4; *(float4*)(mombuf + q) = b4; }
+            if (ue) *(float4*)(ema + q) = e4;
+        } else {
+            for (int k = 0; k < 4; ++k) {
+                const long long i = q + k - off;
+                if (i < 0 || i >= n_total) continue;
+                const bool isp = i < n_params;
+                float p = params[off + i], g = 0.f, b = 0.f, e = 0.f;
+                if (isp) { g = grads[off + i]; if (!first) b = mombuf[off + i]; }
+                if (ue) e = ema[off + i];
+                sgd_ema_elem(p, g, b, e, isp, i < n_decay, first, ue, lr, mom, wd, gscale, d);
+                if (isp) { params[off + i] = p; mombuf[off + i] = b; }
+                if (ue) ema[off + i] = e;
+            }
         }
     }
 }
@@ -306,7 +333,7 @@ __global__ __launch_bounds__(256) void sgd_ema_multi_kernel(float* __restrict__ 
 extern "C" int ydl_sgd_ema_step_multi(float* params, const float* grads, float* momentum, float* ema, const int64_t* runs_dev,
                                       int nruns, int64_t max_run, const float* hyper_dev, int use_ema, void* stream) {
     YDL_CHECK(params && grads && momentum && runs_dev && hyper_dev && nruns > 0 && nruns <= 65535 && max_run >= 0, "bad arguments");
-    long long gx = (max_run + 255) / 256;
+    long long gx = (max_run + 4 + 1023) / 1024;           // four elements per thread (+ the alignment slack of the first group)
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     sgd_ema_multi_kernel<<<dim3((unsigned)gx, (unsigned)nruns), 256, 0, (hipStream_t)stream>>>(params, grads, momentum, ema,
