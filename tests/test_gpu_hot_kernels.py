@@ -121,8 +121,11 @@ TILED = [
     ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3_kernel<128>", "")),
     ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
     # 12 -> 64 channels, 3x3 / s1 on a 16-channel-stride input: the thin-input kernel of the space-to-depth stem
-    ("stem_12_64_bf16", "bf16", 4, 12, 64, 3, 1, 320, 320, ("stem_kernel<bf16,16,64>", "", "", "")),
-    ("stem_12_64_small_bf16", "bf16", 2, 12, 64, 3, 1, 48, 64, ("stem_kernel<bf16,16,64>", "", "", "")),
+    # (its weight gradient: the patch-form stemw_kernel from 65 536 pixels and image widths that are multiples of 64)
+    ("stem_12_64_bf16", "bf16", 4, 12, 64, 3, 1, 320, 320, ("stem_kernel<bf16,16,64>", "", "stemw_kernel", "")),
+    ("stem_12_64_small_bf16", "bf16", 2, 12, 64, 3, 1, 48, 64, ("stem_kernel<bf16,16,64>", "", "wgrad_kernel<bf16,tr>", "")),
+    # ... 13 images of 50 x 128: two 64-pixel segments per row, a stage count (1300) that no CTA count divides
+    ("stem_12_64_ragged_bf16", "bf16", 13, 12, 64, 3, 1, 50, 128, ("stem_kernel<bf16,16,64>", "", "stemw_kernel", "")),
     # ragged: 150 output channels (two channel tiles, the second one partial), odd image size, pixel tail
     ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad3_kernel<128>", "")),
 ]

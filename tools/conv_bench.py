@@ -17,7 +17,8 @@ LAYERS = [(3, 64, 6, 2, 320), (64, 128, 3, 2, 160), (128, 64, 1, 1, 160), (64, 6
           (256, 256, 3, 1, 40), (512, 512, 1, 1, 40), (512, 1024, 3, 2, 20), (512, 512, 3, 1, 20), (2048, 1024, 1, 1, 20),
           (640, 64, 1, 1, 160), (128, 64, 3, 1, 160), (768, 128, 1, 1, 80), (64, 12, 1, 1, 160),
           (64, 64, 1, 1, 160), (64, 128, 1, 1, 160), (128, 256, 1, 1, 80), (256, 64, 1, 1, 80), (512, 128, 1, 1, 40),
-          (1024, 1024, 1, 1, 20), (1024, 512, 1, 1, 20), (256, 256, 1, 1, 80)]
+          (1024, 1024, 1, 1, 20), (1024, 512, 1, 1, 20), (256, 256, 1, 1, 80),
+          (12, 64, 3, 1, 320)]      # [27]: the stem as the model runs it (space-to-depth input, 16 stored channels)
 
 
 def main():

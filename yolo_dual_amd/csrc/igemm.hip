@@ -3390,6 +3390,185 @@ static int launch_wgrad3(const Wgrad2Args& a, dim3 grid, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Weight gradient of the space-to-depth stem (3x3, stride 1, pad 1, 16 stored input channels -> 64 output channels; BASELINE
+// config 2: 16 x 320 x 320 pixels).  K = 9 taps x 16 channels = 144 columns: the tiled kernel above needs TWO 128-column tiles
+// (the second one 16 columns wide: every dY byte is fetched twice, half of the MFMAs multiply zeros) and gathers the nine taps of
+// every pixel separately — 156 us for 262 MB (1.7 TB/s), the last kernel of the backward pass with nothing to overlap.
+// Patch form, like the 3x3 forward kernels: a stage is 64 pixels of ONE output row — dY rows by LDS-DMA in wgrad3's swizzled
+// 128-byte-row image, and the 3 x 66 pixel input patch (32 bytes per pixel, 128 bytes of padding behind every 8 pixels so that
+// the transposed reads of two 8-pixel groups fall into different bank halves) — all nine taps read the same patch at shifted
+// addresses.  Waves: 2 pixel halves (one 32-pixel MFMA K-slice each) x 2 halves of the output channels; a wave owns
+// 32 channels x 9 taps x 16 columns = 18 accumulator tiles.  CTAs are persistent over contiguous stage ranges; at the end the
+// two pixel halves are added through LDS and the CTA adds its 64 x 144 block to dW with atomics (grid x 36 KB).
+// ------------------------------------------------------------------------------------------------------
+#define SW_PROW 3456                    // patch row: 9 groups x (8 pixels x 32 B + 128 B padding)
+#define SW_YBYTES 8192                  // 64 pixels x 128 B
+#define SW_XBYTES 11264                 // 3 patch rows (10368 B) rounded up to whole 1 KiB DMA instructions (11)
+#define SW_STAGE (SW_YBYTES + SW_XBYTES)
+struct StemwArgs {
+    const bf16_t* X; const bf16_t* dY; float* dW;
+    int H, W, segs, ldy, ldw, nstages, chunk;
+    unsigned bytesX, bytesY;
+};
+template <int S>
+__global__ __launch_bounds__(256, 2) void stemw_kernel(const StemwArgs p) {
+    constexpr int L = 5;                        // DMA instructions per wave and stage: 8 (dY) + 11 (patch) + 1 dummy = 20 = 4 x 5
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int h = wave & 1, c = wave >> 1;
+    u32x4 rsX, rsY;
+    {
+        const unsigned long long px = (unsigned long long)p.X, py = (unsigned long long)p.dY;
+        rsX = u32x4{(unsigned)px, (unsigned)(px >> 32) & 0xffffu, p.bytesX, 0x00020000u};
+        rsY = u32x4{(unsigned)py, (unsigned)(py >> 32) & 0xffffu, p.bytesY, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned dump = lds0 + (unsigned)(S * SW_STAGE);             // 1 KiB nobody reads: destination of the dummy instruction
+    // this lane's part of the wave's five instructions i = wave + 4 k: what it fetches is fixed, only the stage origin moves
+    int ykind[L];          // 0 = dY, 1 = patch, 2 = dummy
+    unsigned dst[L];       // LDS offset inside the stage
+    int a0[L], a1[L], a2[L];   // dY: (row, channel offset, -) / patch: (patch row, patch pixel, 16-byte half)
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const int i = wave + 4 * k;
+        if (i < 8) {
+            const int row = 8 * i + (lane >> 3), qs = lane & 7;
+            const int logical = (((qs >> 1) ^ w3f<128>(row)) << 1) | (qs & 1);
+            ykind[k] = 0; dst[k] = (unsigned)i * 1024u; a0[k] = row; a1[k] = logical * 8; a2[k] = 0;
+        } else if (i < 19) {
+            const int o = (i - 8) * 1024 + lane * 16;
+            const int pr = o / SW_PROW, rem = o - pr * SW_PROW;
+            const int grp = rem / 384, b = rem - grp * 384;
+            const int px = grp * 8 + (b >> 5);
+            const bool ok = pr < 3 && b < 256 && px < 66;
+            ykind[k] = 1; dst[k] = (unsigned)SW_YBYTES + (unsigned)(i - 8) * 1024u;
+            a0[k] = ok ? pr : -100000; a1[k] = px; a2[k] = (b >> 4) & 1;
+        } else {
+            ykind[k] = 2; dst[k] = 0; a0[k] = a1[k] = a2[k] = 0;
+        }
+    }
+    const int pbeg = blockIdx.x * p.chunk;
+    const int pend = min(p.nstages, pbeg + p.chunk);
+    // (n * H + r, seg) of the next stage to issue
+    int inr = pbeg / p.segs, iseg = pbeg - inr * p.segs, isidx = pbeg;
+    auto issue = [&](int buf) {
+        const unsigned base = lds0 + (unsigned)buf * (unsigned)SW_STAGE;
+        const bool live = isidx < pend;
+        const int r = inr % p.H;
+        const int c0 = iseg * 64;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            if (ykind[k] == 0) {
+                const unsigned m = (unsigned)(inr * p.W + c0 + a0[k]);
+                lds_dma16(rsY, base + dst[k], live ? (m * (unsigned)p.ldy + (unsigned)a1[k]) * 2u : 0xFFFFFFFFu);
+            } else if (ykind[k] == 1) {
+                const int row = r - 1 + a0[k], col = c0 - 1 + a1[k];
+                const bool ok = live && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+                const unsigned pix = (unsigned)((inr - r + row) * p.W + col);
+                lds_dma16(rsX, base + dst[k], ok ? (pix * 16u + (unsigned)a2[k] * 8u) * 2u : 0xFFFFFFFFu);
+            } else {
+                lds_dma16(rsX, dump, 0xFFFFFFFFu);
+            }
+        }
+        ++isidx;
+        if (++iseg == p.segs) { iseg = 0; ++inr; }
+    };
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) acc[a][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    const int krow = h * 32 + g * 8 + lq;                       // this lane's pixel of the stage (low read; the high read is + 4)
+    auto compute = [&](int cur) {
+        const unsigned char* by = smem + cur * SW_STAGE;
+        const unsigned char* bx = by + SW_YBYTES;
+        uint4 af[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int colb = (c * 32 + a * 16 + lp * 4) * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + w3sw<128>(krow, colb)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + w3sw<128>(krow + 4, colb)));
+            uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+            af[a] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj) {
+                const int pl = krow + tj, ph = pl + 4;
+                const unsigned char* lo_p = bx + ti * SW_PROW + (pl >> 3) * 384 + (pl & 7) * 32 + lp * 8;
+                const unsigned char* hi_p = bx + ti * SW_PROW + (ph >> 3) * 384 + (ph & 7) * 32 + lp * 8;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                const uint4 bf = make_uint4(l2.x, l2.y, h2.x, h2.y);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) Mma<bf16_t>::run(af[a], bf, acc[a][ti * 3 + tj]);
+            }
+    };
+#pragma unroll
+    for (int u = 0; u < S - 1; ++u) issue(u);
+    int buf = 0, nxt = S - 1;
+    for (int s0 = pbeg; s0 < pend; ++s0) {
+        wait_vm_barrier<L * (S - 2)>();
+        issue(nxt);
+        compute(buf);
+        buf = buf + 1 == S ? 0 : buf + 1;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
+    }
+    wait_vm_barrier<0>();
+    // pixel halves: h = 1 parks its tiles in LDS (the ring is dead), h = 0 adds them and owns the atomics
+    f32x4* park = (f32x4*)smem + (size_t)c * 18 * 64;
+    if (h == 1) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) park[(a * 9 + tp) * 64 + lane] = acc[a][tp];
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const f32x4 o = park[(a * 9 + tp) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = c * 32 + a * 16 + (lane >> 4) * 4 + e;
+                    atomicAdd(p.dW + (size_t)co * p.ldw + tp * 16 + (lane & 15), acc[a][tp][e] + o[e]);
+                }
+            }
+    }
+}
+static int g_stemw = 1;
+static bool stemw_ok(const ydl_conv_geom* g, int dtype) {
+    static const int env = getenv("YDL_STEMW") ? atoi(getenv("YDL_STEMW")) : 1;
+    return g_stemw && env && dtype == YDL_BF16 && g->k == 3 && g->s == 1 && g->p == 1 && g->Cin <= 16 && g->Cin > 8 && g->ldx == 16 &&
+           g->Cout == 64 && g->Hi == g->Ho && g->Wi == g->Wo && g->Wo % 64 == 0 && (long)g->N * g->Ho * g->Wo >= 65536;
+}
+static int launch_stemw(const ydl_conv_geom* g, const void* x, const void* dy, float* dw, int ldw, unsigned bx, unsigned by, hipStream_t st) {
+    constexpr int S = 4;
+    StemwArgs a{};
+    a.X = (const bf16_t*)x; a.dY = (const bf16_t*)dy; a.dW = dw;
+    a.H = g->Ho; a.W = g->Wo; a.segs = g->Wo / 64; a.ldy = g->ldy; a.ldw = ldw;
+    a.nstages = g->N * g->Ho * a.segs;
+    static const int ctas = getenv("YDL_STEMW_CTAS") ? atoi(getenv("YDL_STEMW_CTAS")) : 512;
+    a.chunk = (a.nstages + ctas - 1) / ctas;
+    const int grid = (a.nstages + a.chunk - 1) / a.chunk;
+    a.bytesX = bx; a.bytesY = by;
+    const size_t smem = (size_t)S * SW_STAGE + 1024;
+    static_assert((size_t)S * SW_STAGE >= 2 * 18 * 64 * 16, "the parked accumulators reuse the ring");
+    YDL_SET_MAX_LDS((stemw_kernel<S>), smem);
+    ydl_note_kernel(2, "stemw_kernel");
+    stemw_kernel<S><<<grid, 256, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- wgrad launch plan: a pure function of (geometry, dtype, debug knobs); the workspace query and the launch share it
 struct WgradPlan { int kind;     // 0: wgrad_kernel<float>, 1: wgrad_kernel<bf16,tr>, 2: wgrad_kernel<bf16,scalar>, 3: wgrad2<64>, 4: wgrad2<128>
                    int jtiles, ctiles, splits, chunk; };
@@ -3503,6 +3682,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 9 = fused-parity kernel for the k3 s2 p1 data gradients (igemm2s_kernel): 1 (default) on, 0 ring kernel
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
+//              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
 //              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
@@ -3521,6 +3701,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 9) g_s2fused = val;
     if (key == 10) g_resize_int = val;
     if (key == 11) g_resize_rows = val;
+    if (key == 12) g_stemw = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
@@ -3547,6 +3728,7 @@ static int conv_wgrad_impl(const ydl_conv_geom* g, int dtype, const void* x, con
     const int ldw = g->ldw ? g->ldw : ntaps * Kc;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(pl.jtiles * pl.ctiles * pl.splits);
+    if (slab == nullptr && stemw_ok(g, dtype)) return launch_stemw(g, x, dy, dw, ldw, (unsigned)bx, (unsigned)by, st);
     if (pl.kind >= 3) {
         Wgrad2Args a{};
         a.X = (const bf16_t*)x; a.dY = (const bf16_t*)dy; a.dW = dw;
