@@ -3282,6 +3282,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wgrad2Args p) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    int xn[XR], xho[XR], xwo[XR];            // image, output row and column of this thread's XR pixels of the NEXT stage to issue
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const unsigned m = (unsigned)(pbeg + xr + 16 * i);
+        const unsigned n = fastdiv40(m, p.magicHW);
+        const unsigned rem = m - n * (unsigned)HoWo;
+        const unsigned ho = fastdiv40(rem, p.magicW);
+        xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+    }
+    const int adv_h = SP / p.Wo, adv_w = SP - adv_h * p.Wo;      // (wave-uniform; one conditional wrap each: adv_w < Wo, adv_h + 1 <= Ho)
+    const bool slow_decode = adv_h + 1 > p.Ho;
     auto issue = [&](int p0, int buf) {
         const unsigned base = (unsigned)buf * (unsigned)STAGE;
         if (p.dbg == 1) return;
@@ -3294,14 +3305,22 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wgrad2Args p) {
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             const int m = p0 + xr + 16 * i;
-            const unsigned n = fastdiv40((unsigned)m, p.magicHW);
-            const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
-            const unsigned ho = fastdiv40(rem, p.magicW);
-            const unsigned wo = rem - ho * (unsigned)p.Wo;
-            const int ih = (int)ho * p.s + dh, iw = (int)wo * p.s + dw;
+            // (n*Ho + ho, wo) of pixel m are carried from stage to stage (stages are issued in order, SP pixels apart): the two
+            // multiply-shift divisions per DMA made the loop VALU-bound (81 VALU instructions per 16 MFMAs; timing experiment with
+            // a shift/mask decode: 64 -> 128 k3s2 @160^2 118 -> 86 us, 64 -> 64 k3 @160^2 102 -> 66 us)
+            if (slow_decode) {                           // maps narrower than a stage is long (SP / Wo + 1 > Ho): decode by division
+                const unsigned n = fastdiv40((unsigned)m, p.magicHW);
+                const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+                const unsigned ho = fastdiv40(rem, p.magicW);
+                xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+            }
+            const int ih = xho[i] * p.s + dh, iw = xwo[i] * p.s + dw;
             const bool ok = qv && m < pend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            const unsigned off = ok ? (unsigned)(((int)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * 2u : 0xFFFFFFFFu;
+            const unsigned off = ok ? (unsigned)(((xn[i] * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * 2u : 0xFFFFFFFFu;
             lds_dma16(rsX, wave_x + base + (unsigned)i * 4096u, off);
+            xwo[i] += adv_w; xho[i] += adv_h;
+            if (xwo[i] >= p.Wo) { xwo[i] -= p.Wo; xho[i] += 1; }
+            if (xho[i] >= p.Ho) { xho[i] -= p.Ho; xn[i] += 1; }
         }
     };
     const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
