@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="input size (default: the workload's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dcn-offset-std", type=float, default=0.0,
+                    help="DCNv3 workloads: re-draw the offset projections so that the sampling offsets have about this standard deviation "
+                         "in pixels (the module's own initialisation is zero offsets — every point on the grid, the cheapest case)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="keep wgrad on the main stream")
@@ -167,6 +170,16 @@ def main():
         # cfg4 like the reference does and follows --size otherwise
         out_hw = 640 if args.size == 1024 else args.size
         model.img_size = [out_hw, out_hw]
+    if args.dcn_offset_std > 0:
+        gen_o = torch.Generator(device="cpu").manual_seed(77)
+        with torch.no_grad():
+            for mod in model.modules():
+                off = getattr(mod, "offset", None)
+                if off is not None and hasattr(mod, "mask") and hasattr(off, "weight") and off.weight.dim() == 2:
+                    # offset = W x + b over ~unit-variance features: per-element std of W x is about sqrt(in_features) * std(W) * rms(x)
+                    sw = args.dcn_offset_std / (off.weight.shape[1] ** 0.5) / 0.7
+                    off.weight.copy_((torch.randn(off.weight.shape, generator=gen_o) * sw).to(off.weight.device))
+                    off.bias.copy_((torch.randn(off.bias.shape, generator=gen_o) * 0.5 * args.dcn_offset_std).to(off.bias.device))
     cw = torch.tensor(CW, dtype=torch.float32) if wl["cw"] else None
     crit = ydl.SegmentationLoss(12, 0.0, cw, wl["loss"], sync=False)
     # reference hyper-parameters (seg_diceloss_yolov5.py:970-972): lr0 0.01, momentum 0.937, weight_decay 5e-4 * bs*accumulate/64.
