@@ -140,7 +140,7 @@ def test_rank_pinning_splits_the_cpu_set():
         os.sched_setaffinity(0, before)
 
 
-@pytest.mark.parametrize("world,wire", [(2, "f32"), (4, "f32"), (4, "bf16")])
+@pytest.mark.parametrize("world,wire", [(2, "f32"), (4, "f32"), (4, "bf16"), (8, "bf16")])
 def test_reduce_scatter_all_gather_over_all_peers(world, wire):
     """the hand-rolled comparator of RCCL's all-reduce: every rank trades 1/world of each bucket with every peer at
     once, sums in f32 in rank order, and returns its reduced piece to every peer"""
