@@ -2917,7 +2917,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.bytesX, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, p.bytesY, 0x00020000);
     uint4 vy[2], vx[2];
-    // range-checked buffer loads (zeros for padding taps / tail rows), multiply-shift pixel decode
+    // range-checked buffer loads (zeros for padding taps / tail rows).  The (image, row, column) of this thread's two pixels are
+    // decoded once by multiply-shift and then carried from stage to stage (stages are loaded in order, WG_BKP pixels apart): the two
+    // divisions per load were a third of this kernel's VALU instructions (10 per MFMA, round-4 SQ counters)
+    int xn[2], xho[2], xwo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned m = (unsigned)(pbeg + r + 32 * i);
+        const unsigned n = fastdiv40(m, p.magicHW);
+        const unsigned rem = m - n * (unsigned)HoWo;
+        const unsigned ho = fastdiv40(rem, p.magicW);
+        xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+    }
+    const int adv_h = WG_BKP / p.Wo, adv_w = WG_BKP - adv_h * p.Wo;
+    const bool slow_decode = adv_h + 1 > p.Ho;           // maps narrower than a stage is long: decode by division every time
     auto gload = [&](int p0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -2926,15 +2939,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             unsigned offy = (in && yv) ? (unsigned)(m * p.ldy + co_chunk) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
             u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsY, offy, 0, 0);
             vy[i] = make_uint4(a.x, a.y, a.z, a.w);
-            unsigned n = fastdiv40((unsigned)m, p.magicHW);
-            unsigned rem = (unsigned)m - n * (unsigned)HoWo;
-            unsigned ho = fastdiv40(rem, p.magicW);
-            unsigned wo = rem - ho * (unsigned)p.Wo;
-            int ih = (int)ho * p.s + dh, iw = (int)wo * p.s + dw;
+            if (slow_decode) {
+                const unsigned n = fastdiv40((unsigned)m, p.magicHW);
+                const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+                const unsigned ho = fastdiv40(rem, p.magicW);
+                xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+            }
+            int ih = xho[i] * p.s + dh, iw = xwo[i] * p.s + dw;
             bool ok = in && qv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            unsigned offx = ok ? (unsigned)(((int)(n * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
+            unsigned offx = ok ? (unsigned)(((xn[i] * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
             u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsX, offx, 0, 0);
             vx[i] = make_uint4(b.x, b.y, b.z, b.w);
+            xwo[i] += adv_w; xho[i] += adv_h;
+            if (xwo[i] >= p.Wo) { xwo[i] -= p.Wo; xho[i] += 1; }
+            if (xho[i] >= p.Ho) { xho[i] -= p.Ho; xn[i] += 1; }
         }
     };
     gload(pbeg);
