@@ -65,3 +65,22 @@ for npix, C, rows in SHAPES:
                               P(scale), P(shift), 1, None, 0, 0, 1, P(out), C, npix, C, C, st))
     mb = npix * C * 2 / 1e6
     print(f"npix {npix:7d} C {C:5d} | act_fwd_sums {t:6.1f}us {2 * mb / t:5.2f}TB/s", flush=True)
+
+# throughput-mode backward on replica sums (ydl_bn_act_bwd_sums: reduce pass + apply pass; the sums row is zeroed per call like the
+# tape's slab would be)
+print("--- ydl_bn_act_bwd_sums (SiLU, no residual; fill_zero of the sums row included)")
+for npix, C, rows in SHAPES:
+    y = torch.randn(npix, C, device=dev).bfloat16()
+    dout = torch.randn(npix, C, device=dev).bfloat16()
+    dy = torch.empty_like(y)
+    sums = torch.zeros(16, C, device=dev)
+    mean, invstd, scale, shift = (torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev))
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+
+    def run():
+        L.call("ydl_fill_zero", P(sums), sums.numel() * 4, st)
+        L.call("ydl_bn_act_bwd_sums", L.YDL_BF16, P(y), C, P(dout), C, None, 0, P(mean), P(invstd), P(scale), P(shift), 0, 1, P(dy), C, None, 0,
+               P(dg), P(db), 0, P(sums), npix, C, C, st)
+    t = timeit(run)
+    mb = npix * C * 2 / 1e6
+    print(f"npix {npix:7d} C {C:5d} | act_bwd_sums {t:6.1f}us {5 * mb / t:5.2f}TB/s (5 passes)", flush=True)

@@ -538,6 +538,9 @@ extern "C" int ydl_bn_act_bwd(int dtype, const void* y, int ldy, const void* dou
 // finalize and merge launches disappear — 62 launches of 5-9 us per step on BASELINE config 2 — because every consumer thread
 // adds the YDL_BN_REPLICAS partial rows of its own channel chunk itself (L2-resident, a few hundred bytes).
 // ------------------------------------------------------------------------------------------------------
+#ifndef BN_FWD_UNROLL
+#define BN_FWD_UNROLL 4
+#endif
 template <typename T, int ACT, int RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_sums_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ sums, int sums_ld,
                                                               long long count, const float* __restrict__ gamma,
@@ -596,19 +599,34 @@ __global__ __launch_bounds__(256) void bn_act_fwd_sums_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < V; ++e) { sc[e] = s_sc[L.cq * V + e]; sf[e] = s_sf[L.cq * V + e]; }
     const long long stride = (long long)gridDim.x * L.R;
-    for (long long pix = (long long)blockIdx.x * L.R + L.pl; pix < npix; pix += stride) {
-        float v[V], r[V];
-        unpack16<T>(*(const uint4*)(y + pix * ldy + L.c), v);
-        if (RES != YDL_RES_NONE) unpack16<T>(*(const uint4*)(res + pix * ldr + L.c), r);
+    // BN_FWD_UNROLL pixels in flight per thread, and a grid sized (launcher) so that a thread HAS that many: on the 40^2 / 20^2 layers
+    // the former 2048-CTA grid gave every CTA one pixel row after a ~2 us coefficient prologue (8-9 us for 13 MB of traffic)
+    constexpr int U = BN_FWD_UNROLL;
+    for (long long pix0 = (long long)blockIdx.x * L.R + L.pl; pix0 < npix; pix0 += stride * U) {
+        uint4 raw[U], rraw[U];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            float z = v[e] * sc[e] + sf[e];
-            if (RES == YDL_RES_BEFORE_ACT) z += r[e];
-            float o = ACT == YDL_ACT_SILU ? silu_f(z) : (ACT == YDL_ACT_RELU ? fmaxf(z, 0.f) : z);
-            if (RES == YDL_RES_AFTER_ACT) o += r[e];
-            v[e] = o;
+        for (int u = 0; u < U; ++u) {
+            const long long pix = pix0 + u * stride;
+            const long long pc = pix < npix ? pix : pix0;          // (beyond the end: re-read this thread's first pixel, store nothing)
+            raw[u] = *(const uint4*)(y + pc * ldy + L.c);
+            if (RES != YDL_RES_NONE) rraw[u] = *(const uint4*)(res + pc * ldr + L.c);
         }
-        *(uint4*)(out + pix * ldo + L.c) = pack16<T>(v);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long pix = pix0 + u * stride;
+            float v[V], r[V];
+            unpack16<T>(raw[u], v);
+            if (RES != YDL_RES_NONE) unpack16<T>(rraw[u], r);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float z = v[e] * sc[e] + sf[e];
+                if (RES == YDL_RES_BEFORE_ACT) z += r[e];
+                float o = ACT == YDL_ACT_SILU ? silu_f(z) : (ACT == YDL_ACT_RELU ? fmaxf(z, 0.f) : z);
+                if (RES == YDL_RES_AFTER_ACT) o += r[e];
+                v[e] = o;
+            }
+            if (pix < npix) *(uint4*)(out + pix * ldo + L.c) = pack16<T>(v);
+        }
     }
 }
 
@@ -629,6 +647,13 @@ extern "C" int ydl_bn_act_fwd_sums(int dtype, const void* y, int ldy, const floa
     YDL_CHECK(res_mode == YDL_RES_NONE || res_mode == YDL_RES_BEFORE_ACT || res_mode == YDL_RES_AFTER_ACT, "unknown residual mode");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid = lay_grid(npix, Cp, V, 256 * 8);
+    {
+        // BN_FWD_UNROLL pixel rows per CTA pass: no more CTAs than there are passes (every CTA pays the coefficient prologue)
+        static const int small = getenv("YDL_BN_SMALLGRID") ? atoi(getenv("YDL_BN_SMALLGRID")) : 1;
+        const int cpp = Cp / V, cpb = cpp < 256 ? cpp : 256, R = 256 / cpb;
+        const long long want = (npix + (long long)R * BN_FWD_UNROLL - 1) / ((long long)R * BN_FWD_UNROLL);
+        if (small && want < (long long)grid.x) grid.x = (unsigned)(want < 1 ? 1 : want);
+    }
 #define YDL_FS_LAUNCH(T, A, R)                                                                                                      \
     bn_act_fwd_sums_kernel<T, A, R><<<grid, 256, 0, st>>>((const T*)y, ldy, sums, sums_ld, (long long)count, gamma, beta, eps, momentum, \
                                                           running_mean, running_var, mean, invstd, scale, shift, replication,         \
@@ -836,6 +861,18 @@ static int bn_act_bwd_sums_impl(int dtype, const void* y, int ldy, const void* d
     hipStream_t st = (hipStream_t)stream;
     dim3 g1 = lay_grid(npix, Cp, V, BWD_MAX_PARTIALS);
     dim3 g3 = lay_grid(npix, Cp, V, 256 * 8);
+    {
+        // small tensors (40^2 / 20^2 layers): no more CTAs than pixel-row passes of eight (reduce: four 2-pixel iterations and an
+        // eighth of the per-CTA atomic passes) / four (apply) — every CTA pays a coefficient prologue of about 2 us
+        // (tools/bn_bench.py: 6400 x 512 19.8 -> 14.8 us, 6400 x 1024 26.5 -> 22.0 us; no change from 25 600 pixels up)
+        static const int small = getenv("YDL_BN_SMALLGRID") ? atoi(getenv("YDL_BN_SMALLGRID")) : 1;
+        static const int f1 = getenv("YDL_BN_SG_REDUCE") ? atoi(getenv("YDL_BN_SG_REDUCE")) : 8;
+        static const int f3 = getenv("YDL_BN_SG_APPLY") ? atoi(getenv("YDL_BN_SG_APPLY")) : 4;
+        const int cpp = Cp / V, cpb = cpp < 256 ? cpp : 256, R = 256 / cpb;
+        const long long w1 = (npix + (long long)R * f1 - 1) / ((long long)R * f1), w3 = (npix + (long long)R * f3 - 1) / ((long long)R * f3);
+        if (small && w1 < (long long)g1.x) g1.x = (unsigned)(w1 < 1 ? 1 : w1);
+        if (small && w3 < (long long)g3.x) g3.x = (unsigned)(w3 < 1 ? 1 : w3);
+    }
 #define YDL_BS_APPLY(T, A, RM)                                                                                                     \
     bn_bwd_apply_sums_kernel<T, A, RM><<<g3, 256, 0, st>>>((const T*)y, ldy, (const T*)dout, lddo, (const T*)out, ldo, scale, shift, \
                                                            mean, invstd, sums, (T*)dy, lddy, (T*)dres, lddr, dres_acc, dgamma, dbeta, \
