@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #define PW_NB_TS8 2
 #endif
     // pixel tiles in flight per wave (register budget; 512-byte rows x 128-channel waves with statistics AND transposed stores: one less)
-    constexpr int NB = (J >= 8) ? ((TS && STATS && CT == 8 && !ACC) ? PW_NB_TS8 : 3) : PW_NB_SHORT;
+    constexpr int NB = (J >= 8) ? ((CT == 8 && ((STATS && (TS || ACC)) || (TS && ACC))) ? PW_NB_TS8 : 3) : PW_NB_SHORT;
     constexpr int NV = CT * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;                                      // [Cout][RB], chunk q of row r at slot q ^ sw(r)
@@ -1773,10 +1773,38 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     // loads — which also waits for every YOUNGER-but-one prefetch: the NB tiles "in flight" were one (tools/asm_loops.py; round 4).
     // Here every wave runs a multiple of NB steps, tiles beyond its range are out-of-range buffer offsets (loads return zeros,
     // stores are dropped, neither moves data), and the waits come out as vmcnt(NB * J + ...) as intended.
-    if constexpr (!ACC) {
+    {
+        // (ACC: the previous contents of the output tile are FETCHED BEFORE the tile's MFMAs and the prefetch of tile i + NB — in the
+        //  in-order memory counter they are older than the prefetch, so waiting for them leaves the NB x J younger loads in flight;
+        //  fetched after the MFMAs, as the round-3 loop did, the wait drained the whole pipeline)
         const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.Y, 0, p.bytesY, 0x00020000);
+        constexpr int NCH = CT * 16 * ES / 16;          // TS: 16-byte chunks per tile row
+        constexpr int RPP = 64 / NCH;                   // TS: rows per store instruction
         auto step = [&](int i, uint4 (&b)[J], bool prefetch) {
-            asm volatile("" ::: "memory");             // (weight fragments re-read from LDS every step, as below)
+            asm volatile("" ::: "memory");             // the weight fragments are re-read from LDS every step: without this fence the
+                                                       // compiler hoists all J*CT loop-invariant ds_reads into registers (+128 VGPRs)
+            const int tile_m = m_begin + ((i * WP + wp) << 4);
+            u32x4 old_ts[TS ? 16 / RPP : 1];
+            u32x4 old_d4[(!TS && sizeof(T) == 4) ? CT : 1];
+            u32x2 old_d2[(!TS && sizeof(T) == 2) ? CT : 1];
+            if constexpr (ACC) {
+                if constexpr (TS) {
+#pragma unroll
+                    for (int ps = 0; ps < 16 / RPP; ++ps) {
+                        const int row = ps * RPP + lane / NCH, ch = lane % NCH;
+                        const unsigned off = ((unsigned)(tile_m + row) * (unsigned)p.ldc + (unsigned)co0) * ES + (unsigned)(ch << 4);
+                        old_ts[ps] = __builtin_amdgcn_raw_buffer_load_b128(rsY, tile_m + row < m_end ? off : 0xFFFFFFFFu, 0, 0);
+                    }
+                } else {
+                    const int m = tile_m + lrow;
+                    const unsigned off = m < m_end ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(co0 + lgrp * 4)) * ES : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        if constexpr (sizeof(T) == 4) old_d4[c] = __builtin_amdgcn_raw_buffer_load_b128(rsY, off, c * 16 * ES, 0);
+                        else old_d2[c] = __builtin_amdgcn_raw_buffer_load_b64(rsY, off, c * 16 * ES, 0);
+                    }
+                }
+            }
             f32x4 acc[CT];
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1790,10 +1818,10 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
                 for (int c = 0; c < CT; ++c) Mma<T>::run(af[c], b[j], acc[c]);
             }
             if (prefetch) load(i + NB, b);
-            const int tile_m = m_begin + ((i * WP + wp) << 4);
             if constexpr (TS) {
-                constexpr int NCH = CT * 16 * ES / 16;          // 16-byte chunks per tile row
-                constexpr int RPP = 64 / NCH;                   // rows per store instruction
+                // The accumulator layout gives a lane 4 consecutive channels of one pixel: a direct store writes a pixel row
+                // in 8-byte pieces from CT different instructions.  Transposed through a wave-private LDS tile (no barrier: one
+                // wave's LDS operations complete in order) every lane stores 16 bytes and NCH neighbouring lanes one whole row.
                 unsigned char* tb = stage + wave * (16 * NCH * 16);
                 const int swm = (NCH - 1) & 15;
 #pragma unroll
@@ -1812,7 +1840,15 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #pragma unroll
                 for (int ps = 0; ps < 16 / RPP; ++ps) {
                     const int row = ps * RPP + lane / NCH, ch = lane % NCH;
-                    const uint4 v4 = *(const uint4*)(tb + row * (NCH * 16) + ((ch ^ (row & swm)) << 4));
+                    uint4 v4 = *(const uint4*)(tb + row * (NCH * 16) + ((ch ^ (row & swm)) << 4));
+                    if constexpr (ACC) {          // gradient fan-in: whole 16-byte read-modify-write rows (launcher: bf16, no statistics)
+                        float a8[16 / ES], o8[16 / ES];
+                        unpack16<T>(v4, a8);
+                        unpack16<T>(make_uint4(old_ts[ps].x, old_ts[ps].y, old_ts[ps].z, old_ts[ps].w), o8);
+#pragma unroll
+                        for (int e = 0; e < 16 / ES; ++e) a8[e] += o8[e];
+                        v4 = pack16<T>(a8);
+                    }
                     const unsigned off = ((unsigned)(tile_m + row) * (unsigned)p.ldc + (unsigned)co0) * ES + (unsigned)(ch << 4);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{v4.x, v4.y, v4.z, v4.w}, rsY, tile_m + row < m_end ? off : 0xFFFFFFFFu, 0, 0);
                 }
@@ -1822,9 +1858,17 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     if constexpr (sizeof(T) == 4) {
+                        if constexpr (ACC) {
+                            acc[c][0] += __uint_as_float(old_d4[c].x); acc[c][1] += __uint_as_float(old_d4[c].y);
+                            acc[c][2] += __uint_as_float(old_d4[c].z); acc[c][3] += __uint_as_float(old_d4[c].w);
+                        }
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[c][0]), __float_as_uint(acc[c][1]), __float_as_uint(acc[c][2]),
                                                                      __float_as_uint(acc[c][3])}, rsY, off, c * 16 * ES, 0);
                     } else {
+                        if constexpr (ACC) {
+                            acc[c][0] += __uint_as_float(old_d2[c].x << 16); acc[c][1] += __uint_as_float(old_d2[c].x & 0xffff0000u);
+                            acc[c][2] += __uint_as_float(old_d2[c].y << 16); acc[c][3] += __uint_as_float(old_d2[c].y & 0xffff0000u);
+                        }
                         u32x2 w2;
                         w2.x = (uint32_t)f2bf(acc[c][0]) | ((uint32_t)f2bf(acc[c][1]) << 16);
                         w2.y = (uint32_t)f2bf(acc[c][2]) | ((uint32_t)f2bf(acc[c][3]) << 16);
@@ -1832,7 +1876,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
                     }
                 }
             }
-            if (want_stats) {                           // (rows beyond the range are zeros: they add nothing to the sums)
+            if (want_stats) {       // statistics of the stored f32 values (including an accumulated y); rows beyond the range are zeros
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -1851,111 +1895,6 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #pragma unroll
         for (int u = 0; u < NB - 1; ++u)                    // the last nsteps % NB tiles (their loads were issued above; nothing follows them)
             if (nfull + u < nsteps) step(nfull + u, bq[u], false);
-    } else
-    for (int i0 = 0; i0 < nsteps; i0 += NB) {
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int i = i0 + u;
-            if (i < nsteps) {
-                // the weight fragments are re-read from LDS every step: without this fence the compiler hoists all
-                // J*CT loop-invariant ds_reads into registers (+128 VGPRs => one wave per SIMD, or spills)
-                asm volatile("" ::: "memory");
-                f32x4 acc[CT];
-#pragma unroll
-                for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const int koff = (((j << 2) | lgrp) ^ swr) << 4;
-                    uint4 af[CT];
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(wbase + c * 16 * RB + koff);
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) Mma<T>::run(af[c], bq[u][j], acc[c]);
-                }
-                if (i + NB < nsteps) load(i + NB, bq[u]);
-                const int m = m_begin + ((i * WP + wp) << 4) + lrow;
-                if constexpr (TS) {
-                    // The accumulator layout gives a lane 4 consecutive channels of one pixel: a direct store writes a pixel row
-                    // in 8-byte pieces from CT different instructions.  Transposed through a wave-private LDS tile (no barrier: one
-                    // wave's LDS operations complete in order) every lane stores 16 bytes and NCH neighbouring lanes one whole row.
-                    constexpr int NCH = CT * 16 * ES / 16;          // 16-byte chunks per tile row
-                    constexpr int RPP = 64 / NCH;                   // rows per store instruction
-                    unsigned char* tb = stage + wave * (16 * NCH * 16);
-                    const int swm = (NCH - 1) & 15;
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        if constexpr (sizeof(T) == 4) {
-                            const int ch = c * 4 + lgrp;
-                            *(float4*)(tb + lrow * (NCH * 16) + ((ch ^ (lrow & swm)) << 4)) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
-                        } else {
-                            const int ch = c * 2 + (lgrp >> 1);
-                            uint2 w2;
-                            w2.x = (uint32_t)f2bf(acc[c][0]) | ((uint32_t)f2bf(acc[c][1]) << 16);
-                            w2.y = (uint32_t)f2bf(acc[c][2]) | ((uint32_t)f2bf(acc[c][3]) << 16);
-                            *(uint2*)(tb + lrow * (NCH * 16) + ((ch ^ (lrow & swm)) << 4) + ((lgrp & 1) << 3)) = w2;
-                        }
-                    }
-                    const int tile_m = m_begin + ((i * WP + wp) << 4);
-#pragma unroll
-                    for (int ps = 0; ps < 16 / RPP; ++ps) {
-                        const int row = ps * RPP + lane / NCH, ch = lane % NCH;
-                        uint4 v4 = *(const uint4*)(tb + row * (NCH * 16) + ((ch ^ (row & swm)) << 4));
-                        if (tile_m + row < m_end) {
-                            uint4* gp = (uint4*)((unsigned char*)(Yg + (size_t)(tile_m + row) * p.ldc + co0) + (ch << 4));
-                            if (p.accumulate) {          // gradient fan-in: whole 16-byte read-modify-write rows (launcher: bf16, no statistics)
-                                float a8[16 / ES], o8[16 / ES];
-                                unpack16<T>(v4, a8);
-                                unpack16<T>(*gp, o8);
-#pragma unroll
-                                for (int e = 0; e < 16 / ES; ++e) a8[e] += o8[e];
-                                v4 = pack16<T>(a8);
-                            }
-                            *gp = v4;
-                        }
-                    }
-                    if (want_stats && m < m_end) {
-#pragma unroll
-                        for (int c = 0; c < CT; ++c)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                s1[c * 4 + e] += acc[c][e];
-                                s2[c * 4 + e] = fmaf(acc[c][e], acc[c][e], s2[c * 4 + e]);
-                            }
-                        cnt += 1.f;
-                    }
-                } else if (!TS && m < m_end) {
-                    T* dst = Yg + (size_t)m * p.ldc + co0 + lgrp * 4;
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        float v[4] = {acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
-                        if constexpr (sizeof(T) == 4) {
-                            float4* d4 = (float4*)(dst + c * 16);
-                            if (p.accumulate) { float4 o = *d4; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                            *d4 = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-                            uint2* d2 = (uint2*)(dst + c * 16);
-                            if (p.accumulate) {
-                                uint2 o = *d2;
-                                v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-                                v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
-                            }
-                            uint2 w2;
-                            w2.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                            w2.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                            *d2 = w2;
-                        }
-                        if (want_stats) {       // statistics of the stored f32 values (including an accumulated y)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                s1[c * 4 + e] += v[e];
-                                s2[c * 4 + e] = fmaf(v[e], v[e], s2[c * 4 + e]);
-                            }
-                        }
-                    }
-                    if (want_stats) cnt += 1.f;
-                }
-            }
-        }
     }
 
     if (want_stats) {
@@ -2262,8 +2201,10 @@ static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int 
         YDL_SET_MAX_LDS((pw_kernel<T, RB, CT, NW, TS_, ACC_, ST_>), 160 * 1024);      \
         pw_kernel<T, RB, CT, NW, TS_, ACC_, ST_><<<pl.grid_m, NW * 64, sm, st>>>(a2); \
     } while (0)
-    if (a2.accumulate) {
+    if (a2.accumulate && a2.stats) {
         if (a2.tstore) PW_LAUNCH(true, true, true); else PW_LAUNCH(false, true, true);
+    } else if (a2.accumulate) {
+        if (a2.tstore) PW_LAUNCH(true, true, false); else PW_LAUNCH(false, true, false);
     } else if (a2.stats) {
         if (a2.tstore) PW_LAUNCH(true, false, true); else PW_LAUNCH(false, false, true);
     } else {
