@@ -105,6 +105,71 @@ def cpu_baseline(wl: dict, bs: int, size: int, steps: int):
             "sample": f"{steps} timed steps (1 warm-up) of the same model/loss/optimizer at bs={bs}, {size}x{size}, fp32"}
 
 
+def spawn_ranks(n: int) -> int:
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in proc.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(f"[bench] {n}-rank launch failed: exit code {proc.returncode}, {len(lines)} result lines", file=sys.stderr)
+        return proc.returncode or 1
+    print(lines[0])
+    return 0
+
+
+def parity_leg(ydl, args, wl, dev, imgs, tgts, out_hw):
+    """A bounded leg of the SAME workload in parity mode (f32 storage and arithmetic, deterministic weight gradients): the mode every
+    1e-4 claim against the reference is made in.  Fresh model and optimizer, eager launches (26 ms of GPU time per step hide the host),
+    timed like the main region."""
+    import torch
+    ydl.set_compute_dtype("f32")
+    try:
+        torch.manual_seed(0)
+        if wl["model"] == "ResNet50Seg":
+            model = ydl.ResNet50Seg({"nc": 12}).to(dev).train()
+        else:
+            model = getattr(ydl, wl["model"])(load_cfg(wl["yaml"], wl["swap"])).to(dev).train()
+            model.img_size = [out_hw, out_hw]
+        cw = torch.tensor(CW, dtype=torch.float32) if wl["cw"] else None
+        crit = ydl.SegmentationLoss(12, 0.0, cw, wl["loss"], sync=False)
+        opt = ydl.FlatSGDEMA(model, lr=0.01, momentum=0.937, weight_decay=5e-4 * args.bs / 64.0)
+
+        def step():
+            opt.zero_grad()
+            out = model(imgs)
+            loss, items = crit(out, tgts)
+            loss.backward()
+            opt.step(grad_scale=1.0)
+            return items
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.parity_steps):
+            items = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ips = args.bs * args.parity_steps / dt
+        flop_img = wl["flop_img"] if (wl["flop_img"] and args.size == wl["size"]) else None
+        return {"dtype": "f32", "value": ips, "unit": "images/sec", "steps": args.parity_steps, "ms_per_step": dt / args.parity_steps * 1e3,
+                "launch_mode": "eager", "loss": float(items[0]),
+                "end_to_end_mfma_frac": (ips * flop_img / 1e12 / PEAK_F32) if flop_img else None,
+                "note": "same workload, f32 storage + exact-f32 MFMA, deterministic weight gradients; peak = 157.3 TFLOP/s f32 matrix"}
+    finally:
+        ydl.set_compute_dtype(args.dtype)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,11 +196,21 @@ def main():
     ap.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="gradient exchange: RCCL all-reduce (default) or the hand-rolled reduce-scatter + all-gather over all peers")
     ap.add_argument("--dp-wire", default="f32", choices=["f32", "bf16"], help="wire format of the gradients")
+    ap.add_argument("--dp-serial-phase2", action="store_true",
+                    help="rs_ag: run each bucket's all-gather at the end of backward instead of overlapping it (the round-3 form)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip the bounded f32 (parity-mode) leg after the timed region")
+    ap.add_argument("--parity-steps", type=int, default=5)
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     args.bs = args.bs or wl["bs"]
     args.size = args.size or wl["size"]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly: start the N ranks ourselves (one process per GPU under torch.distributed.run, the way the reference starts
+        # its DDP runs, utils/torch_utils.py:55-63) BEFORE anything here touches the GPU, pass rank 0's JSON line through, and fail
+        # if any worker fails.  The child is a fresh interpreter, never an exec of this one.
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -187,6 +262,8 @@ def main():
     # round(64/16) = 4 batches at bs 16), which is what the formula is evaluated with here.
     opt = ydl.FlatSGDEMA(model, lr=0.01, momentum=0.937, weight_decay=5e-4 * args.bs * world / 64.0, ema=(rank == 0))
     dp = DataParallel(model, opt, algo=args.dp_algo, wire=args.dp_wire) if world > 1 else None
+    if dp and args.dp_serial_phase2:
+        dp.reducer.overlap_phase2 = False
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     imgs = torch.rand(args.bs, 3, args.size, args.size, device=dev, generator=g)
@@ -334,13 +411,8 @@ def main():
             f = fam.setdefault(r["name"], {"ms": 0.0, "flops": 0.0, "n": 0, "bytes": 0.0})
             f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["n"] += 1; f["bytes"] += r.get("bytes", 0.0)
         tot_ms = sum(f["ms"] for f in fam.values())
+        # headline = the family with the largest GPU time in THIS run, whichever it is (every family's own figure is in "by_kernel_roofline")
         dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        # The headline kernel stays the forward convolution (ydl_conv_fwd_sums, the one the earlier rounds' lines and reviews name)
-        # while it is within 15 % of the largest family — forward, data-gradient and weight-gradient convolutions are three
-        # near-equal shares and the largest of them changes from box to box; every family's own figure is in "by_kernel_roofline"
-        pref = fam.get("ydl_conv_fwd_sums")
-        if pref is not None and pref["ms"] >= 0.85 * dom[1]["ms"]:
-            dom = ("ydl_conv_fwd_sums", pref)
         name, f = dom
         traffic = None
         import glob
@@ -395,6 +467,16 @@ def main():
         roof["flop_per_image_executed"] = exec_flop_img
         roof["end_to_end_mfma_frac"] = ips / world * flop_img / 1e12 / peak
 
+    parity = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_parity_leg:
+        rstep = gstep = None                # the recorded step's private pool is not needed any more
+        torch.cuda.synchronize()
+        try:
+            parity = parity_leg(ydl, args, wl, dev, imgs, tgts, out_hw)
+        except Exception as e:              # pragma: no cover  (the leg must never take the headline down with it)
+            parity = {"dtype": "f32", "error": repr(e)}
+            torch.cuda.synchronize()
+
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(wl, 2, args.size, args.cpu_steps if args.size <= 640 else 1)
@@ -409,7 +491,7 @@ def main():
             "config": {"workload": f"{wl['desc']}, fwd+bwd+SGD/EMA step, {args.size}x{args.size}, bs={args.bs}/GPU, "
                                    f"CE+0.5*{wl['loss'].capitalize()}, 12 classes ({wl['base']})", "name": args.workload,
                        "global_batch": args.bs * world, "parallelism": f"dp{world}"},
-            "roofline": roof, "cpu_baseline": base}))
+            "roofline": roof, "parity_mode": parity, "cpu_baseline": base}))
     if world > 1:
         dist.destroy_process_group()
 

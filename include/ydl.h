@@ -311,6 +311,13 @@ int ydl_dcnv3_fwd(int dtype, const void* input, const void* offset, const void* 
                   int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
                   int dilation_h, int dilation_w, int group, int group_channels, float offset_scale,
                   int N, int H_in, int W_in, int H_out, int W_out, void* stream);
+/* Border rule of the sampling positions (process-wide, read at launch time), the one case where the reference has two answers:
+ *   0 (default)  a position exactly at -1 is inside, ">= -1": dcnv3_core_pytorch, functions/dcnv3_func.py:148-189 (F.grid_sample,
+ *                padding zeros) — the form of the op the oracle and every golden vector of this repo come from;
+ *   1            "> -1" as the CUDA op tests it, dcnv3_im2col_cuda.cuh:262,334,428: such a point has no value and no gradient.
+ * A binding that replaces DCNv3Function's CUDA extension selects 1 once at import time. */
+void ydl_dcnv3_set_border_rule(int rule);
+int ydl_dcnv3_get_border_rule(void);
 /* grad_input must be zeroed by the caller (f32 atomics); grad_offset/grad_mask are fully written. */
 int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, const void* mask, const void* grad_output,
                   float* grad_input, float* grad_offset, float* grad_mask,

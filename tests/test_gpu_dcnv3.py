@@ -171,3 +171,105 @@ def test_c3_dcnv3(name, mode):
     finally:
         ydl.set_compute_dtype("bf16")
 
+
+
+def _dcn_bwd_raw(dt, inp, off, msk, go, gin, G, Gc, pad=1):
+    """ydl_dcnv3_bwd through the C ABI on caller-owned buffers (k 3, stride 1, dilation 1, offset_scale 1)"""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    from yolo_dual_amd.tape import _p, _stream
+    N, H, W, _ = inp.shape
+    goff = torch.empty(off.shape, dtype=torch.float32, device="cuda")
+    gmsk = torch.empty(msk.shape, dtype=torch.float32, device="cuda")
+    L.call("ydl_dcnv3_bwd", dt, _p(inp), _p(off), _p(msk), _p(go), _p(gin), _p(goff), _p(gmsk), 3, 3, 1, 1, pad, pad, 1, 1, G, Gc,
+           ctypes.c_float(1.0), N, H, W, H, W, _stream())
+    torch.cuda.synchronize()
+    return goff, gmsk
+
+
+@pytest.mark.parametrize("sigma", [0.0, 2.0])
+def test_dcnv3_backward_stays_inside_grad_input(sigma):
+    """Guard for the class of bug behind round 4's GPU memory fault (a window cell flushed to an address no bounds test had vouched
+    for): at the benchmark's shape (N 16, 80 x 80, G 4, Gc 64, bf16; zero offsets and sigma = 2 px) grad_input is carved out of a
+    larger canary-filled buffer.  The margins must come back untouched — an out-of-bounds atomic that lands inside the allocator's
+    block is invisible to the GPU's page protection — and the register-window kernel must equal the plain per-corner kernel
+    (ydl_debug_set key 13) up to the order of the f32 atomic adds."""
+    from yolo_dual_amd import _lib as L
+    N, H, W, G, Gc = 16, 80, 80, 4, 64
+    C = G * Gc
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    inp = torch.randn(N, H, W, C, device="cuda", generator=gen).bfloat16()
+    off = (torch.randn(N, H, W, G * 18, device="cuda", generator=gen) * sigma).bfloat16()
+    msk = torch.softmax(torch.randn(N, H, W, G, 9, device="cuda", generator=gen), -1).reshape(N, H, W, G * 9).bfloat16()
+    go = torch.randn(N, H, W, C, device="cuda", generator=gen).bfloat16()
+    margin = 8 * W * C                                     # eight image rows on either side
+    n_el = N * H * W * C
+    canary = 12345.678
+    res = {}
+    try:
+        for win in (1, 0):
+            L.debug_set(13, win)
+            big = torch.full((margin + n_el + margin,), canary, dtype=torch.float32, device="cuda")
+            gin = big[margin:margin + n_el].view(N, H, W, C)
+            gin.zero_()
+            goff, gmsk = _dcn_bwd_raw(L.YDL_BF16, inp, off, msk, go, gin, G, Gc)
+            assert bool((big[:margin] == canary).all()) and bool((big[margin + n_el:] == canary).all()), \
+                f"grad_input's margins were written (window kernel {win})"
+            res[win] = (gin.clone(), goff, gmsk)
+    finally:
+        L.debug_set(13, 1)
+    scale = float(res[0][0].abs().max())
+    assert float((res[1][0] - res[0][0]).abs().max()) <= 1e-4 * scale            # same products, different summation order
+    assert torch.equal(res[1][1], res[0][1]) or float((res[1][1] - res[0][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max())
+    assert float((res[1][2] - res[0][2]).abs().max()) <= 1e-5 * float(res[0][2].abs().max())
+
+
+@pytest.mark.parametrize("Gc", [16, 64])          # 16: the plain kernel (several items per wave); 64: the register-window kernel
+def test_dcnv3_border_rule_pins_both_conventions(Gc):
+    """A sampling position EXACTLY at -1 (every border tap of the module's own initialisation: zero offsets, pad 1) has two answers in
+    the reference.  Rule "core" (default): inside — value 0, offset gradient = the one-sided slope, as dcnv3_core_pytorch /
+    F.grid_sample give it (functions/dcnv3_func.py:148-189): checked against the CPU oracle's autograd.  Rule "cuh": outside, as
+    dcnv3_im2col_cuda.cuh:262,334,428 test it (`loc > -1`): no offset / mask gradient at those taps, everything else unchanged."""
+    import yolo_dual_amd as ydl
+    from oracle import ref_cpu as R
+    from yolo_dual_amd import _lib as L
+    N, H, W, G = 2, 6, 7, 2
+    C = G * Gc
+    g = torch.Generator().manual_seed(3)
+    inp = torch.randn(N, H, W, C, generator=g)
+    off = torch.zeros(N, H, W, G * 18)
+    off[:, 2:4, 2:5] = torch.randn(N, 2, 3, G * 18, generator=g) * 0.3          # interior pixels get real offsets
+    msk = torch.softmax(torch.randn(N, H, W, G, 9, generator=g), -1).reshape(N, H, W, G * 9)
+    go = torch.randn(N, H, W, C, generator=g)
+    ri, ro, rm = (t.clone().requires_grad_(True) for t in (inp, off, msk))
+    (R.dcnv3_core(ri, ro, rm, 3, 3, 1, 1, 1, 1, 1, 1, G, Gc, 1.0) * go).sum().backward()
+    # taps whose position is exactly -1 in h or w: point (i over w, j over h), position = pixel - 1 + i (w) / - 1 + j (h) + offset
+    P = 9
+    wo = torch.arange(W).view(1, 1, W, 1, 1).float()
+    ho = torch.arange(H).view(1, H, 1, 1, 1).float()
+    pi = (torch.arange(P) // 3).view(1, 1, 1, 1, P).float()
+    pj = (torch.arange(P) % 3).view(1, 1, 1, 1, P).float()
+    o6 = off.view(N, H, W, G, P, 2)
+    edge = ((wo - 1 + pi + o6[..., 0]) == -1) | ((ho - 1 + pj + o6[..., 1]) == -1)
+    assert int(edge.sum()) > 0
+    try:
+        out = {}
+        for rule in ("core", "cuh"):
+            ydl.config.set_dcnv3_border_rule(rule)
+            assert ydl.config.dcnv3_border_rule() == rule
+            gin = torch.zeros(N, H, W, C, device="cuda")
+            goff, gmsk = _dcn_bwd_raw(L.YDL_F32, inp.cuda(), off.cuda(), msk.cuda(), go.cuda(), gin, G, Gc)
+            out[rule] = (gin.cpu(), goff.cpu().view(N, H, W, G, P, 2), gmsk.cpu().view(N, H, W, G, P))
+    finally:
+        ydl.config.set_dcnv3_border_rule("core")
+    tol = lambda r: dict(rtol=1e-3, atol=max(1e-5, 2e-5 * float(r.abs().max())))
+    # core rule = the oracle, everywhere
+    assert torch.allclose(out["core"][0], ri.grad, **tol(ri.grad))
+    assert torch.allclose(out["core"][1], ro.grad.view(N, H, W, G, P, 2), **tol(ro.grad))
+    assert torch.allclose(out["core"][2], rm.grad.view(N, H, W, G, P), **tol(rm.grad))
+    assert float(out["core"][1][edge].abs().max()) > 0          # the one-sided slope is really there
+    # .cuh rule: nothing at the taps exactly at -1, the oracle's values elsewhere; grad_input is the same (those taps carry weight 0)
+    assert float(out["cuh"][1][edge].abs().max()) == 0.0 and float(out["cuh"][2][edge].abs().max()) == 0.0
+    assert torch.allclose(out["cuh"][1][~edge], ro.grad.view(N, H, W, G, P, 2)[~edge], **tol(ro.grad))
+    assert torch.allclose(out["cuh"][2][~edge], rm.grad.view(N, H, W, G, P)[~edge], **tol(rm.grad))
+    assert torch.allclose(out["cuh"][0], ri.grad, **tol(ri.grad))

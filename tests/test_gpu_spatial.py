@@ -100,3 +100,29 @@ def test_row_walking_resize_forward_equals_the_element_indexed_kernel(dtype, mod
         finally:
             L.debug_set(11, 1)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_given_scale_that_is_not_the_size_ratio_takes_the_generic_backward():
+    """A caller-given scale (tape.resize passes the yaml Upsample's scale_factor; the C ABI takes scale_h / scale_w) need not equal
+    Hi / Ho although the sizes look like an integer factor: scale_factor 2.05 on 12 columns gives floor(24.6) = 24 = 2 x 12, but output
+    23 then maps to source 10.96 and references input 10 — outside the integer-factor kernel's fixed 2S window.  The dispatch must fall
+    back to the generic gather; reference: torch's interpolate with the same scale_factor, float64."""
+    from yolo_dual_amd import _lib as L
+    sf = 2.05
+    N, Hi, Wi, C = 2, 10, 12, 16
+    Ho, Wo = int(Hi * sf), int(Wi * sf)
+    assert (Ho, Wo) == (20, 24)
+    gen = torch.Generator("cuda").manual_seed(11)
+    dy = torch.randn(N, Ho, Wo, C, device="cuda", generator=gen)
+    dx = torch.zeros(N, Hi, Wi, C, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.call("ydl_resize_bwd", L.YDL_F32, 1, P(dy), C, P(dx), C, 0, N, Hi, Wi, Ho, Wo, C, ctypes.c_float(1.0 / sf), ctypes.c_float(1.0 / sf), st)
+    torch.cuda.synchronize()
+    x = torch.zeros(N, C, Hi, Wi, device="cuda", dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.interpolate(x, scale_factor=sf, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+    assert tuple(y.shape[-2:]) == (Ho, Wo)
+    y.backward(dy.permute(0, 3, 1, 2).double())
+    ref = x.grad.permute(0, 2, 3, 1)
+    err = float((dx.double() - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err

@@ -68,6 +68,7 @@ def parse_opt(argv=None):
                    "through the GPU letterbox (yolo_dual_amd.data.LetterboxGPU = the dataset's _resize_and_pad + /255)")
     p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend when WORLD_SIZE > 1 (nccl = RCCL; gloo for rehearsals)")
     p.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"])
+    p.add_argument("--dp-serial-phase2", action="store_true", help="rs_ag: all-gathers at the end of backward, not overlapped with it")
     p.add_argument("--dp-wire", default="f32", choices=["f32", "bf16"])
     p.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --dist-backend gloo)")
     p.add_argument("--emulate-world", type=int, default=0, help="debugging aid (single process): play N data-parallel ranks in turn — rank "
@@ -180,6 +181,8 @@ def train(opt) -> float:
     if world > 1:                                                                        # :988-992, as processes instead of threads
         from yolo_dual_amd.parallel import DataParallel
         dp = DataParallel(model, optimizer, algo=opt.dp_algo, wire=opt.dp_wire)          # broadcasts rank 0's parameters and buffers
+        if opt.dp_serial_phase2:
+            dp.reducer.overlap_phase2 = False
     if opt.cos_lr:
         lf = lambda x: ((1 - math.cos(x * math.pi / epochs)) / 2) * (opt.lrf - 1) + 1     # one_cycle(1, lrf, epochs)
     else:

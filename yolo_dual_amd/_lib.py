@@ -99,6 +99,8 @@ SIGNATURES = {
     "ydl_sgd_ema_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp]),
     "ydl_sgd_ema_step_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _i, _vp]),
     "ydl_confusion_matrix": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ydl_dcnv3_set_border_rule": (None, [_i]),
+    "ydl_dcnv3_get_border_rule": (_i, []),
     "ydl_dcnv3_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp]),
     "ydl_dcnv3_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f,
                            _i, _i, _i, _i, _i, _vp]),

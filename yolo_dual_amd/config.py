@@ -129,6 +129,21 @@ def set_bn_bwd_fuse(on: bool) -> None:
     _STATE["bn_bwd_fuse"] = bool(on)
 
 
+def set_dcnv3_border_rule(rule: str) -> None:
+    """Which of the reference's two answers a DCNv3 sampling position EXACTLY at -1 gets (include/ydl.h: ydl_dcnv3_set_border_rule):
+    "core" (default) = inside, as the pure-PyTorch core `dcnv3_core_pytorch` and the oracle have it (functions/dcnv3_func.py:148-189);
+    "cuh" = outside, as the CUDA op tests it (dcnv3_im2col_cuda.cuh:262,334,428) — what a drop-in for the compiled extension selects."""
+    from . import _lib as L
+    if rule not in ("core", "cuh"):
+        raise ValueError("rule must be 'core' or 'cuh'")
+    L.lib().ydl_dcnv3_set_border_rule(1 if rule == "cuh" else 0)
+
+
+def dcnv3_border_rule() -> str:
+    from . import _lib as L
+    return "cuh" if L.lib().ydl_dcnv3_get_border_rule() else "core"
+
+
 def replicated_loss() -> bool:
     """SegmentationLoss evaluates a nearest-replicated prediction per stored pixel (ydl_seg_loss_rep_*)"""
     return _STATE["replicated_loss"]

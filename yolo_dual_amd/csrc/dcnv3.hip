@@ -3,10 +3,13 @@
 // the decomposition is ours: a (pixel, group) item is owned by a power-of-two lane segment of one wavefront
 // (lanes = group channels, so every NHWC access is a contiguous run), and the grad_offset / grad_mask sums over the
 // channels are wavefront-shuffle butterflies instead of the reference's shared-memory trees.
-// One measure-zero case is decided by the oracle (functions/dcnv3_func.py:148-189, the pure-PyTorch core — the only form of the op
-// the reference can run without its missing binding): a sampling point EXACTLY at -1 is inside (">= -1"; the .cuh tests "> -1").
-// Its value is zero either way, but its offset gradient is the one-sided slope towards pixel 0, as grid_sample's backward gives —
-// with the module's own initialisation (offset weights zero, pad 1) every border tap sits exactly there.
+// One measure-zero case has TWO conventions in the reference, selectable here (ydl_dcnv3_set_border_rule):
+//   rule 0 (default) — the pure-PyTorch core, functions/dcnv3_func.py:148-189 (the only form of the op the reference can run without
+//     its missing binding, hence the oracle): a sampling point EXACTLY at -1 is inside (">= -1").  Its value is zero either way, but
+//     its offset gradient is the one-sided slope towards pixel 0, as grid_sample's backward gives;
+//   rule 1 — the CUDA op, dcnv3_im2col_cuda.cuh:262,334,428: "loc > -1" — a point exactly at -1 is outside: no value, no gradient.
+// With the module's own initialisation (offset weights zero, pad 1) every border tap sits exactly at -1, so the two rules give
+// different offset-bias gradients on the first step.
 #include "common.h"
 #include <stdlib.h>
 
@@ -37,7 +40,20 @@ struct DcnArgs {
     int N, H, W, Ho, Wo;
     int seg;          // lanes per item (power of two, <= 64)
     long long items;  // N*Ho*Wo*G
+    int strict;       // border rule: 0 ">= -1" (PyTorch core), 1 "> -1" (.cuh)
 };
+
+static int g_dcn_border_rule = 0;
+static int g_dcn_win = 1;          // ydl_debug_set key 13 (YDL_DCN_NOWIN=1 at start-up switches the window backward off)
+extern "C" void ydl_dcnv3_set_border_rule(int rule) { g_dcn_border_rule = rule ? 1 : 0; }
+extern "C" int ydl_dcnv3_get_border_rule(void) { return g_dcn_border_rule; }
+void ydl_dcn_debug_set(int key, int val) { if (key == 13) g_dcn_win = val; }
+
+// inside test of a sampling position: lower edge by the selected rule, upper edge exclusive in both conventions
+__device__ __forceinline__ bool dcn_inside(float lh_, float lw_, int H, int W, int strict) {
+    const bool lo = strict ? (lh_ > -1.f && lw_ > -1.f) : (lh_ >= -1.f && lw_ >= -1.f);
+    return lo && lh_ < (float)H && lw_ < (float)W;
+}
 
 __device__ __forceinline__ float seg_sum(float v, int seg) {
     for (int o = seg >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(256) void dcnv3_kernel(const DcnArgs a) {
                     float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
                     float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
                     float gmask = 0.f, goffw = 0.f, goffh = 0.f;
-                    if (lh_ >= -1.f && lw_ >= -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
+                    if (dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {
                         int hl = (int)floorf(lh_), wl = (int)floorf(lw_);
                         int hh_ = hl + 1, wh_ = wl + 1;
                         float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
@@ -182,6 +198,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
             const int c = c0 + lane;
             const bool act = c < a.Gc;
             const float go = act ? ET<T>::ld((const T*)a.gout + (size_t)pix * C + g * a.Gc + c) : 0.f;
+            static_assert(25 <= 32, "one bit of `touched` per window cell");
             float win[25];
 #pragma unroll
             for (int q = 0; q < 25; ++q) win[q] = 0.f;
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
                     const float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
                     const float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
                     float gmask = 0.f, goffw = 0.f, goffh = 0.f;
-                    if (lh_ >= -1.f && lw_ >= -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {          // (uniform)
+                    if (dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {          // (uniform)
                         const int hl = __builtin_amdgcn_readfirstlane((int)floorf(lh_)), wl = __builtin_amdgcn_readfirstlane((int)floorf(lw_));
                         const int hh_ = hl + 1, wh_ = wl + 1;
                         const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
@@ -244,8 +261,14 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
             touched = __builtin_amdgcn_readfirstlane(touched);
 #pragma unroll
             for (int q = 0; q < 25; ++q)
-                if ((touched >> q) & 1u) {                                       // (uniform) touched cells lie inside the image
-                    if (act) atomicAdd(gib + ((size_t)(hb + q / 5) * a.W + (wb + q % 5)) * C + c, win[q]);
+                if ((touched >> q) & 1u) {
+                    // (uniform) a bit is only set for a corner that passed its own bounds test (b1..b4), so the cell lies inside the
+                    // image; the test below costs two scalar compares and makes that a property of THIS loop, not of the code above
+                    // (the withdrawn 7 x 7 form kept 49 cells behind this 32-bit mask: `1u << q` wrapped for q >= 32, marked cells that
+                    // no corner had vouched for, and border pixels then flushed to rows in front of the tensor — the round-4 GPU fault)
+                    const int fh = hb + q / 5, fw = wb + q % 5;
+                    if (act && (unsigned)fh < (unsigned)a.H && (unsigned)fw < (unsigned)a.W)
+                        atomicAdd(gib + ((size_t)fh * a.W + fw) * C + c, win[q]);
                 }
         }
     }
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_vec_kernel(const DcnArgs a) {
                         const float ow = offp[2 * k], oh = offp[2 * k + 1], mk = mskp[k];
                         const float lw_ = p0w_ + ((float)(i * a.dw) + ow) * a.scale;
                         const float lh_ = p0h_ + ((float)(j * a.dh) + oh) * a.scale;
-                        if (act && lh_ >= -1.f && lw_ >= -1.f && lh_ < (float)a.H && lw_ < (float)a.W) {
+                        if (act && dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {
                             const int hl = (int)floorf(lh_), wl = (int)floorf(lw_);
                             const int hh_ = hl + 1, wh_ = wl + 1;
                             const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
@@ -349,6 +372,7 @@ static int fill_args(DcnArgs& a, int kernel_h, int kernel_w, int stride_h, int s
     while (seg < group_channels && seg < 64) seg <<= 1;
     a.seg = seg;
     a.items = (long long)N * H_out * W_out * group;
+    a.strict = g_dcn_border_rule;
     return 0;
 }
 
@@ -410,7 +434,7 @@ extern "C" int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, c
     hipStream_t st = (hipStream_t)stream;
     YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16 || dtype == YDL_F16, "bad dtype");
     static const int nowin = getenv("YDL_DCN_NOWIN") ? atoi(getenv("YDL_DCN_NOWIN")) : 0;
-    if (!nowin && kernel_h == 3 && kernel_w == 3 && a.seg == 64) {
+    if (!nowin && g_dcn_win && kernel_h == 3 && kernel_w == 3 && a.seg == 64) {
         // a whole wave per item: corner gradients merged in a register window before the atomics (dcnv3_bwd_win_kernel)
         long long blocks = (a.items + 3) / 4;
         if (blocks > 256 * 8) blocks = 256 * 8;

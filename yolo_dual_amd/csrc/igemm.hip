@@ -737,7 +737,13 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NW, int WP, int S, bool RED = false>
+// STG (round 5): the eight waves of the CTA as two HALVES that run half a K-step apart.  Waves i and i + 4 share a SIMD; in the
+// plain form both reach their fragment reads, their DMA issue and their MFMAs together, so the matrix pipe idles while both load and
+// both queue for it afterwards.  Here waves 0-3 run   barrier_k | read(k) | issue | MFMA(k)          and waves 4-7 run
+// barrier_k | MFMA(k-1) | issue | read(k)   — the younger half keeps a whole K-step of fragments in registers across the barrier and
+// computes it while the older half loads: on every SIMD one wave is in its matrix segment while its partner is in its LDS / DMA
+// segment.  Same barrier count, same DMA count per thread and step (the counted vmcnt is unchanged), results bit-identical.
+template <int BM, int BN, int NW, int WP, int S, bool RED = false, int STG = 0>
 __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const IgemmArgs p) {
     using T = bf16_t;
     constexpr int ES = 2;
@@ -901,6 +907,43 @@ __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const
 #pragma unroll
             for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
     };
+    if constexpr (STG != 0) {
+        static_assert(NW == 8, "the stagger splits the CTA into waves 0-3 and 4-7");
+        auto rd_step = [&](int stg) { rdfrag(stg, 0, af0, bf0); rdfrag(stg, 1, af1, bf1); };
+        auto mma_step = [&]() { mma(af0, bf0); mma(af1, bf1); };
+        if (wave < NW / 2) {
+            int stg = 0;
+            for (int kk = 0; kk < nk; ++kk) {
+                wait_vm_barrier<L * (S - 2)>();                // step kk landed everywhere; every wave holds step kk-1 in registers
+                rd_step(stg);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(stg == 0 ? S - 1 : stg - 1);             // step kk+S-1 -> the stage step kk-1 occupied
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step();
+                __builtin_amdgcn_sched_barrier(0);
+                stg = stg + 1 == S ? 0 : stg + 1;
+            }
+        } else if (nk > 0) {
+            if (STG == 2) __builtin_amdgcn_s_setprio(1);
+            wait_vm_barrier<L * (S - 2)>();
+            issue(S - 1);
+            rd_step(0);
+            int stg = 1 % S;
+            for (int kk = 1; kk < nk; ++kk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // step kk-1 is in registers: its stage may be overwritten
+                wait_vm_barrier<L * (S - 2)>();
+                mma_step();                                             // step kk-1, while waves 0-3 read step kk
+                __builtin_amdgcn_sched_barrier(0);
+                issue(stg == 0 ? S - 1 : stg - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_step(stg);
+                __builtin_amdgcn_sched_barrier(0);
+                stg = stg + 1 == S ? 0 : stg + 1;
+            }
+            mma_step();
+            if (STG == 2) __builtin_amdgcn_s_setprio(0);
+        }
+    } else {
     if (nk > 0) {
         wait_vm_barrier<L * (S - 2)>();            // step 0 landed everywhere
         issue(S - 1);
@@ -923,6 +966,8 @@ __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const
             }
         }
     }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wait_vm_barrier<0>();              // the trailing all-zero DMAs must land before the epilogue reuses the LDS
     if (p.dbg == 3) {                  // timing experiment: keep the accumulators live, skip stores and statistics
         float sink = 0.f;
@@ -2262,7 +2307,7 @@ struct TileCfg { int BM, BN; int ring; };     // ring != 0: igemm2_kernel (bf16 
 static int g_ring_enabled = 1;
 static int g_ring_persist = 1;
 
-template <int BM, int BN, int NW, int WP, int S, bool RED = false>
+template <int BM, int BN, int NW, int WP, int S, bool RED = false, int STG = 0>
 static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
     a.grid_n = (a.Cst + BN - 1) / BN;
     int mtiles = (a.M + BM - 1) / BM;
@@ -2291,8 +2336,8 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
     }
     const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int) + (RED ? BN * 16 : 0);
     static const std::string nm = std::string("igemm2_kernel<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
-                                  std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + (RED ? ",bnred>" : ">");
-    if constexpr (S == 2) {
+                                  std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + (RED ? ",bnred>" : (STG ? ",stg>" : ">"));
+    if constexpr (S == 2 && STG == 0) {
         // persistent form (igemm2p_kernel): worth it when a CTA gets more than one tile; needs n_k >= 2 in every class
         static const int persist = getenv("YDL_RING_PERSIST") ? atoi(getenv("YDL_RING_PERSIST")) : 1;
         const int spt = a.Kc >> 6;
@@ -2319,16 +2364,16 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
             return 0;
         }
     }
-    YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S, RED>), smem);
+    YDL_SET_MAX_LDS((igemm2_kernel<BM, BN, NW, WP, S, RED, STG>), smem);
     ydl_note_kernel(fam, nm.c_str());
-    igemm2_kernel<BM, BN, NW, WP, S, RED><<<grid, NW * 64, smem, st>>>(a);
+    igemm2_kernel<BM, BN, NW, WP, S, RED, STG><<<grid, NW * 64, smem, st>>>(a);
     YDL_LAUNCH_CHECK();
     return 0;
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128};
 // patch-form 3x3 / stride-1 kernel (igemm2h_kernel): eligibility and launch
 static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
 static bool halo_ok(const IgemmArgs& a, int id) {
@@ -2450,6 +2495,11 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         case 11: return launch_igemm2<128, 64, 4, 2, 2>(a, st, fam);      // 48 KB: three CTAs per CU (64-channel outputs)
         case 12: return launch_igemm2<128, 64, 4, 4, 2>(a, st, fam);      // 48 KB, 32x64 wave tiles
         case 13: return launch_igemm2<128, 64, 8, 4, 2>(a, st, fam);      // 48 KB, 8 waves of 32x32
+        case 14: return launch_igemm2<128, 128, 8, 4, 2, false, 1>(a, st, fam);   // staggered halves (round 5)
+        case 15: return launch_igemm2<256, 128, 8, 4, 3, false, 1>(a, st, fam);   // 256x128, 64x64 wave tiles, 144 KB: one CTA per CU
+        case 16: return launch_igemm2<256, 128, 8, 4, 2, false, 1>(a, st, fam);   // the same with two stages (96 KB)
+        case 17: return launch_igemm2<128, 128, 8, 4, 2, false, 2>(a, st, fam);   // staggered + s_setprio 1 for the younger half
+        case 18: return launch_igemm2<256, 128, 8, 4, 3, false, 2>(a, st, fam);
     }
     ydl_set_error("internal: unknown ring kernel id");
     return 1;
@@ -3661,13 +3711,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
+//              key 13 = DCNv3 backward with the register window (dcnv3_bwd_win_kernel): 1 (default) on, 0 plain per-corner atomics
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
 //              key 4 = 128-wide bf16 weight-gradient kernel: 1 (default) LDS-DMA feed (wgrad3_kernel), 0 register-staged (wgrad2_kernel)
 // Process-wide and test-only: they change launch geometry, so callers that cache ydl_conv_fwd_grid_m/... must drop the cache
 // after a change (yolo_dual_amd._lib.debug_set does).
 extern int g_resize_int, g_resize_rows;       // spatial.hip
+void ydl_dcn_debug_set(int key, int val);     // dcnv3.hip
 extern "C" void ydl_debug_set(int key, int val) {
+    ydl_dcn_debug_set(key, val);
     if (key == 0) g_wgrad_tr = val;
     if (key == 1) g_pw_enabled = val;
     if (key == 2) g_dgrad_merge = val;

@@ -667,8 +667,11 @@ extern "C" int ydl_resize_bwd(int dtype, int mode, const void* dy, int lddy, voi
     float sh = axis_scale(mode, Hi, Ho, scale_h), sw = axis_scale(mode, Wi, Wo, scale_w);
     hipStream_t st = (hipStream_t)stream;
     int grid = sgrid((long long)N * Hi * Wi * (Cp / V));
-    if (g_resize_int && mode == 1 && Ho == Wo / Wi * Hi && Wo % Wi == 0 && (Wo / Wi == 2 || Wo / Wi == 4) && Ho == Hi * (Wo / Wi)) {
-        const int S = Wo / Wi;
+    // (the fixed 2S-candidate window of the integer-factor kernel holds every referencing output only for the EXACT scale 1/S: a
+    // caller-given scale_factor such as 2.05 still yields Ho = 2 Hi by flooring, but maps outputs outside that window — generic path)
+    const int Sq = (Wi > 0 && Wo % Wi == 0) ? Wo / Wi : 0;
+    if (g_resize_int && mode == 1 && (Sq == 2 || Sq == 4) && Ho == Hi * Sq && sh == 1.f / (float)Sq && sw == 1.f / (float)Sq) {
+        const int S = Sq;
         // (the accumulation order over the candidates equals the generic kernel's: rows outer, columns inner, ascending)
         if (dtype == YDL_F32) {
             if (S == 2) resize_bwd_int_kernel<float, 2><<<grid, 256, 0, st>>>((const float*)dy, lddy, (float*)dx, lddx, accumulate, N, Hi, Wi, Cp, sh, sw);

@@ -948,10 +948,13 @@ class Linear(YdlModule):
         return tape.linear(x, self)
 
 
-def _is_power_of_2(n):
-    if (not isinstance(n, int)) or (n < 0):
-        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
-    return (n & (n - 1) == 0) and n != 0
+def _lanes_per_group_channel_block(gc: int) -> int:
+    """lanes one (pixel, group) item of the DCNv3 kernels occupies: the next power of two >= the group's channel count, at most a
+    wavefront (csrc/dcnv3.hip: fill_args) — the idle share of those lanes is what a non-power-of-two head width costs here"""
+    seg = 1
+    while seg < gc and seg < 64:
+        seg <<= 1
+    return seg
 
 
 class DCNv3(YdlModule):
@@ -964,10 +967,14 @@ class DCNv3(YdlModule):
         super().__init__()
         if channels % group != 0:
             raise ValueError(f"channels must be divisible by group, but got {channels} and {group}")
-        if not _is_power_of_2(channels // group):
+        gc = channels // group
+        seg = _lanes_per_group_channel_block(gc)
+        lanes = -(-gc // seg) * seg                # lanes x passes an item takes
+        if lanes != gc:
+            # (the reference warns at the same place, modules/dcnv3.py:75-79, about its own kernel; here the cost is idle lanes)
             import warnings
-            warnings.warn("You'd better set channels in DCNv3 to make the dimension of each attention head a power of 2 "
-                          "which is more efficient in our CUDA implementation.")
+            warnings.warn(f"DCNv3: {gc} channels per group run as {lanes // seg} pass(es) of {seg}-lane segments in the HIP sampling "
+                          f"kernels ({lanes - gc} of {lanes} lane slots idle); a power of two up to 64, or a multiple of 64, wastes none.")
         self.offset_scale = offset_scale
         self.channels = channels
         self.kernel_size = kernel_size

@@ -232,7 +232,12 @@ class GradBucketReducer:
         # The all-gather of bucket k is posted when bucket k + 1 is launched (its reduce-scatter has had a bucket's worth of backward
         # to complete), not at the end of backward: phase 2 of every bucket but the last overlaps the remaining backward.  The point
         # is a fixed place in the program, NOT "whenever is_completed() turns true": point-to-point messages between two ranks are
-        # matched in posting order, so every rank must post P1(0) P2(0) P1(1) P2(1) ... in the same order.
+        # matched in posting order, so every rank must post in the same order.  The order that runs (the reduce-scatter of bucket
+        # k + 1 was posted a few lines up, BEFORE this call completes bucket k's phase 1 and posts its phase 2):
+        #     P1(0)  P1(1) P2(0)  P1(2) P2(1)  ...  P1(n-1) P2(n-2)  | _drain: P2(n-1)
+        # — the same on every rank because the bucket plan and the launch points are.  Hardware status: exercised on gloo (world 2,
+        # 4, 8) and with two ranks on one GPU only; RCCL has not seen this path with more than one rank, so
+        # ``overlap_phase2 = False`` stays selectable from the command line (bench.py / train_seg.py --dp-serial-phase2).
         if self.overlap_phase2:
             self._advance_phase1()
         self._phase1.append((hs, post2, fin2))
@@ -272,6 +277,7 @@ class GradBucketReducer:
                 fin2()
             self._phase1 = []
         self._phase2 = []
+        assert not self._phase1 and not self._phase2 and not self._handles and not self._post, "a bucket exchange is still pending"
 
     # ------------------------------------------------------------------ end of backward
     def finish(self) -> float:
