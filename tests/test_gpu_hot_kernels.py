@@ -103,23 +103,26 @@ TILED = [
     # 3x3 / stride 1 with the image a multiple of 8 x 16: the patch-form kernel (activation patch loaded once per channel block)
     ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2h_kernel<128,128,2>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<128>", "")),
     # ... the same layer on a 152 x 152 image (not a multiple of 16): the ring kernel
-    ("k3_128x128_ring_bf16", "bf16", 4, 128, 128, 3, 1, 152, 152, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
+    ("k3_128x128_ring_bf16", "bf16", 4, 128, 128, 3, 1, 152, 152, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3_kernel<128>", "")),
+    # ... at 3 x 128 x 128 (192 tiles of 128 x 128, 96 of 256 x 128): too few tiles for the one-CTA-per-CU form, the 128 x 128 / 64 x 128 ring
+    ("k3_128x128_ring_small_bf16", "bf16", 3, 128, 128, 3, 1, 120, 136, ("igemm2_kernel<", "igemm2_kernel<", "", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
     ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<64>", "")),
-    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
+    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3_kernel<64>", "")),
     # one channel block: the single-patch-buffer form (four CTAs per CU)
     ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
     # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
     ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
-    ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
+    ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2s_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
     # ... a dy grid of 88 x 88 (not a multiple of 16): the ring kernel, one launch over the four classes
     ("k3s2_64_128_ring_bf16", "bf16", 8, 64, 128, 3, 2, 176, 176, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
     ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
-    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
+    # (forward: 400 tiles of 256 x 128, 36 K-steps: the staggered one-CTA-per-CU form; the strided dgrad's parity classes stay on 128 x 128)
+    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
     # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
     ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3_kernel<128>", "")),
-    ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad_kernel<bf16,tr>", "")),
+    ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad_kernel<bf16,tr>", "")),
     # 12 -> 64 channels, 3x3 / s1 on a 16-channel-stride input: the thin-input kernel of the space-to-depth stem
     # (its weight gradient: the patch-form stemw_kernel from 65 536 pixels and image widths that are multiples of 64)
     ("stem_12_64_bf16", "bf16", 4, 12, 64, 3, 1, 320, 320, ("stem_kernel<bf16,16,64>", "", "stemw_kernel", "")),
@@ -510,3 +513,72 @@ def test_dgrad_with_fused_bn_backward_reduce(case):
         got = sums.view(L.BN_REPLICAS, 2, cw).double().sum(0)
         err = float((got - ref).abs().max() / ref.abs().max())
         assert err < 2e-4, (tag, c0, err)
+
+
+@pytest.mark.parametrize("acc_path", [1, 2])          # ydl_debug_set key 14: 1 = transposed stores + row-layout statistics, 2 = direct stores
+@pytest.mark.parametrize("cin,cout,N,H,W,expect", [(128, 128, 4, 128, 128, "pw_kernel<bf16,256,4,4,"), (256, 256, 4, 128, 128, "pw_kernel<bf16,512,8,8,"),
+                                                    (64, 128, 5, 120, 112, "pw_kernel<bf16,128,4,4,")])
+def test_accumulating_pointwise_forward_with_statistics_through_the_c_abi(cin, cout, N, H, W, expect, acc_path):
+    """ydl_conv_fwd_sums(accumulate = 1) on the point-wise streaming kernel: y += W x with the BatchNorm (sum, sum of squares) replica rows of
+    the FINAL y — the second launch of the commuted Concat + 1x1 Conv of the live head (seg_diceloss_yolov5.py:484-507 + :388-409), the
+    instantiations bench.py runs (`pw_kernel<bf16,256,4,4,*,acc,stats>`, `<bf16,512,8,8,*,acc,stats>`).  Reference: float64 on the same
+    bf16 operands.  Both store paths: the per-wave transposed one (round 5: statistics taken in the row layout; its own contribution is
+    rounded to bf16 before the add — one rounding more) and the direct read-modify-write one."""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    rs = np.random.RandomState(cin + cout + acc_path)
+    x = torch.from_numpy((rs.standard_normal((N, H, W, cin)) + 0.25).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rs.standard_normal((cout, cin)) / np.sqrt(cin)).astype(np.float32)).bfloat16()
+    y0 = torch.from_numpy(rs.standard_normal((N, H, W, cout)).astype(np.float32)).bfloat16()
+    ref = y0.double() + x.double() @ w.double().t()
+    dev = torch.device("cuda")
+    xg, wg, yg = x.to(dev), w.view(cout, 1, cin).contiguous().to(dev), y0.clone().to(dev)
+    sums = torch.zeros(8, 2, cout, device=dev)                       # YDL_BN_REPLICAS rows of (sum, sum of squares)
+    g = L.ConvGeom(N, H, W, cin, H, W, cout, 1, 1, 0, cin, cout)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.debug_set(14, acc_path)
+    try:
+        L.call("ydl_conv_fwd_sums", ctypes.byref(g), L.YDL_BF16, P(xg), P(wg), P(yg), P(sums), 1, st)
+        torch.cuda.synchronize()
+        name = L.last_kernel(0)
+    finally:
+        L.debug_set(14, -1)
+    assert name.startswith(expect) and name.endswith(",ts>" if acc_path == 1 else ",direct>"), name
+    got = yg.cpu().double()
+    assert l2_err(got, ref) < 6e-3, l2_err(got, ref)
+    assert float((got - ref).abs().max()) < 2.5e-2 * float(ref.abs().max())
+    tot = sums.double().sum(0).cpu()
+    r1, r2 = ref.reshape(-1, cout).sum(0), (ref * ref).reshape(-1, cout).sum(0)
+    # the sums are of the f32 values before the final rounding (transposed path: own contribution already bf16-rounded)
+    # (a sum of n values carrying independent 2^-9 roundings is off by about 2^-9 x rms x sqrt(n) = 2^-9 x sqrt(sum of squares))
+    assert float(((tot[0] - r1).abs() / r2.sqrt()).max()) < 5e-3, float(((tot[0] - r1).abs() / r2.sqrt()).max())
+    assert float(((tot[1] - r2) / r2).abs().max()) < 2e-3, float(((tot[1] - r2) / r2).abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W,expect", [(128, 128, 2, 32, 48, "igemm2h_kernel<128,128,2>"), (64, 64, 3, 24, 32, "igemm2h_kernel<128,64,2>"),
+                                                    (64, 128, 2, 40, 32, "igemm2h_kernel<128,64,3>")])
+def test_accumulating_patch_form_dgrad_through_the_c_abi(cin, cout, N, H, W, expect):
+    """ydl_conv_dgrad(accumulate = 1) of a 3x3 / stride 1 / pad 1 convolution on the patch-form kernels (the read-modify-write pre-pass of
+    igemm2_epilogue behind igemm2hs_kernel — two patch buffers, the one-channel-block form — and igemm2h_kernel<64, 3 stages>), which
+    the whole-model tests reach in f32 only: float64 reference on the same bf16 operands (seg_diceloss_yolov5.py:388-409 backward)."""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    rs = np.random.RandomState(cin * 3 + cout)
+    dy = torch.from_numpy(rs.standard_normal((N, cout, H, W)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cout)).astype(np.float32)).bfloat16()
+    dx0 = torch.from_numpy(rs.standard_normal((N, cin, H, W)).astype(np.float32)).bfloat16()
+    ref = torch.nn.grad.conv2d_input((N, cin, H, W), w.double(), dy.double(), stride=1, padding=1) + dx0.double()
+    dev = torch.device("cuda")
+    dy_g = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    wt_g = w.permute(1, 2, 3, 0).reshape(cin, 9, cout).contiguous().to(dev)       # [Cin][tap][Cout]
+    dx_g = dx0.permute(0, 2, 3, 1).contiguous().to(dev)
+    g = L.ConvGeom(N, H, W, cin, H, W, cout, 3, 1, 1, cin, cout)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.call("ydl_conv_dgrad", ctypes.byref(g), L.YDL_BF16, P(dy_g), P(wt_g), P(dx_g), 1, st)
+    torch.cuda.synchronize()
+    assert L.last_kernel(1) == expect, L.last_kernel(1)
+    got = dx_g.float().permute(0, 3, 1, 2).cpu().double()
+    assert l2_err(got, ref) < 4e-3, l2_err(got, ref)
+    assert float((got - ref).abs().max()) < 1.6e-2 * float(ref.abs().max())

@@ -1806,9 +1806,13 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
     const unsigned char* const wbase = sW + (co0 + lrow) * RB;
     const int swr = CPR == 8 ? (lrow >> 1) & 7 : lrow;
     T* const Yg = (T*)p.Y;
-    float s1[NV], s2[NV];
+    // TS && ACC && STATS (round 5: the accumulating forward launch of the commuted Concat + 1x1 Conv, y += W a with statistics): the final
+    // values exist in the ROW layout of the transposed store (a lane = 16 bytes = 8 channels of one pixel, always the same 8 channels),
+    // so the statistics are per-lane (sum, sum of squares) of 8 channels there: 16 registers instead of 2 x CT x 4.
+    constexpr bool ROWSTATS = TS && ACC && STATS && sizeof(T) == 2;
+    float s1[ROWSTATS ? 8 : NV], s2[ROWSTATS ? 8 : NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { s1[v] = 0.f; s2[v] = 0.f; }
+    for (int v = 0; v < (ROWSTATS ? 8 : NV); ++v) { s1[v] = 0.f; s2[v] = 0.f; }
     float cnt = 0.f;
     const bool want_stats = STATS && p.stats != nullptr;      // (STATS = false: the input-gradient launches — 2 x CT x 4 registers less)
 
@@ -1893,6 +1897,12 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
 #pragma unroll
                         for (int e = 0; e < 16 / ES; ++e) a8[e] += o8[e];
                         v4 = pack16<T>(a8);
+                        if constexpr (ROWSTATS) {          // rows beyond the range: contribution and old value are both zeros
+                            if (want_stats) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { s1[e] += a8[e]; s2[e] = fmaf(a8[e], a8[e], s2[e]); }
+                            }
+                        }
                     }
                     const unsigned off = ((unsigned)(tile_m + row) * (unsigned)p.ldc + (unsigned)co0) * ES + (unsigned)(ch << 4);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{v4.x, v4.y, v4.z, v4.w}, rsY, tile_m + row < m_end ? off : 0xFFFFFFFFu, 0, 0);
@@ -1921,7 +1931,7 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
                     }
                 }
             }
-            if (want_stats) {       // statistics of the stored f32 values (including an accumulated y); rows beyond the range are zeros
+            if (!ROWSTATS && want_stats) {       // statistics of the stored f32 values (including an accumulated y); rows beyond the range are zeros
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -1942,6 +1952,41 @@ __global__ __launch_bounds__(NW * 64) void pw_kernel(const PwArgs p) {
             if (nfull + u < nsteps) step(nfull + u, bq[u], false);
     }
 
+    if constexpr (ROWSTATS) {
+        if (want_stats) {
+            constexpr int NCH = CT * 16 * ES / 16;
+            // lanes with equal (lane % NCH) hold the same 8 channels: butterfly over the others, then the pixel waves through LDS
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int o = NCH; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+            __syncthreads();                                  // every wave is done with its store tiles: sred takes their place
+            if (lane < NCH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = wc * CT * 16 + lane * 8 + e;
+                    sred[((size_t)wp * p.Cout + ch) * 2] = s1[e];
+                    sred[((size_t)wp * p.Cout + ch) * 2 + 1] = s2[e];
+                }
+            }
+            __syncthreads();
+            for (int ch = t; ch < p.Cout; ch += NW * 64) {
+                float a = 0.f, b = 0.f;
+                for (int w = 0; w < WP; ++w) { a += sred[((size_t)w * p.Cout + ch) * 2]; b += sred[((size_t)w * p.Cout + ch) * 2 + 1]; }
+                if (p.stats_atomic) {
+                    float* dst = p.stats + (size_t)(blockIdx.x & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
+                    atomicAdd(dst + ch, a);
+                    atomicAdd(dst + p.stats_ld + ch, b);
+                } else {                                      // partial-row contract: (sum, M2) of this block's m_end - m_begin values
+                    const float n = (float)(m_end - m_begin);
+                    float* dst = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld;
+                    dst[ch] = a;
+                    dst[p.stats_ld + ch] = fmaxf(b - a * a / fmaxf(n, 1.f), 0.f);
+                }
+            }
+        }
+        return;
+    }
     if (want_stats) {
         if constexpr (TS) __syncthreads();                   // every wave is done with its store tiles: sred takes their place
         // per-lane (count, mean, M2), then Chan-merge over the 16 pixel lanes: stage s pairs lanes that differ in bit s;
@@ -2174,6 +2219,8 @@ static bool args_stem(const IgemmArgs& a) {
 
 struct PwPlan { bool ok; int RB, CT, WN, NW, block_m, grid_m; size_t smem, tstage; };
 static int g_pw_enabled = 1;
+static int g_pw_acc_ts = -1;     // ydl_debug_set key 14: accumulating point-wise launches: 1 transposed stores (statistics in the row layout),
+                                 // 2 transposed stores only without statistics, 0 direct stores; -1 = YDL_PW_ACC_TS / default 1
 static int g_dgrad_merge = 1;
 // eligibility + launch geometry; a pure function of its arguments (the stats-workspace queries call it too)
 static PwPlan pw_plan(int M, int Kc, int Cout, int Cst, int es, bool pointwise) {
@@ -2216,10 +2263,13 @@ static int launch_pw_cfg(const PwArgs& a, const PwPlan& pl, hipStream_t st, int 
     // (bf16 only: the f32 instantiations lose an occupancy step or spill with the extra staging code; parity mode keeps direct stores)
     // (an accumulating launch takes the transposed path when it carries no statistics: the input-gradient fan-in.  Its own
     //  contribution is rounded to bf16 in the staging tile before the add — one rounding more than the direct path.)
-    static const int acc_ts = getenv("YDL_PW_ACC_TS") ? atoi(getenv("YDL_PW_ACC_TS")) : 1;
+    static const int acc_ts_env = getenv("YDL_PW_ACC_TS") ? atoi(getenv("YDL_PW_ACC_TS")) : 1;
+    const int acc_ts = g_pw_acc_ts >= 0 ? g_pw_acc_ts : acc_ts_env;       // ydl_debug_set key 14
     // measured per layer (tools/conv_bench.py dgrad --acc 1): faster everywhere (-8 ... -27 %) but on 256-byte K rows with 128-channel
     // wave tiles, where the direct read-modify-write wins (128->128 @160^2: 90 vs 111 us)
-    const bool acc_ok = a.stats == nullptr && acc_ts && !(RB == 256 && CT == 8);
+    // (round 5: with statistics too, bf16 — they are taken in the row layout of the transposed store, see ROWSTATS in the kernel;
+    //  YDL_PW_ACC_TS=2 keeps the statistics launches on the direct path)
+    const bool acc_ok = (a.stats == nullptr || (sizeof(T) == 2 && acc_ts == 1)) && acc_ts && !(RB == 256 && CT == 8);
     const size_t wbytes = (size_t)a.Cout * RB;
     const size_t ts_smem = wbytes + (pl.tstage > pl.smem - wbytes ? pl.tstage : pl.smem - wbytes);
     // (512-byte rows x 128-channel waves: the transposed stores fit the register file only without the statistics' 64 registers)
@@ -2378,7 +2428,7 @@ static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 
 static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
 static bool halo_ok(const IgemmArgs& a, int id) {
     static const int env = getenv("YDL_HALO") ? atoi(getenv("YDL_HALO")) : 1;
-    if (!env || !g_halo || (id != 7 && id != 13) || a.br.nseg > 0) return false;
+    if (!env || !g_halo || (id != 7 && id != 13 && id != 15) || a.br.nseg > 0) return false;
     if (a.ncls > 1 || a.ntaps != 9 || a.Ttot != 9 || a.in_mul != 1 || a.out_mul != 1 || a.out_h0 != 0 || a.out_w0 != 0) return false;
     if (a.Hi != a.Ho || a.Wi != a.Wo || a.Hg != a.Ho || a.Wg != a.Wo || (a.Ho & 7) || (a.Wo & 15) || (a.Kc & 63)) return false;
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
@@ -2469,7 +2519,7 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         // weight ring depth: 6 stages x 16 KB + two patches = 144 KB, one CTA per CU with five weight steps in flight; 64-wide tiles
         // 3 stages x 8 KB = 72 KB, two CTAs per CU (YDL_HALO_S: tuning)
         static const int hs = getenv("YDL_HALO_S") ? atoi(getenv("YDL_HALO_S")) : 0;
-        if (id == 7) {
+        if (id == 7 || id == 15) {
             if (hs == 3) return launch_igemm2h<128, 3>(a, st, fam);
             if (hs == 6) return launch_igemm2h<128, 6>(a, st, fam);
             return launch_igemm2h<128, 2>(a, st, fam);
@@ -2506,7 +2556,7 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
 }
 
 // Tile choice: a pure function of (M, Cst, K chunks, dtype) — the stats-workspace queries call it too.
-static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int Kc = 0, int taps = 0) {
+static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int Kc = 0, int taps = 0, bool one_class = true) {
     TileCfg c;
     c.ring = 0;
     // 64..127 stored output channels: 128x64 tile, 8 waves, 2 stages = 48 KB (three CTAs per CU).  Measured against the register-staged
@@ -2521,6 +2571,15 @@ static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int 
         static const int forced = getenv("YDL_RING") ? atoi(getenv("YDL_RING")) : -1;      // tuning: force an instantiation id
         const long b128 = (long)((M + 127) / 128) * ((Cst + 127) / 128);
         int id = b128 < 256 ? 9 : 7;
+        // Round 5: 256 x 128 tile, 64 x 64 wave tiles, three stages (144 KB: ONE CTA per CU) with the two wave halves staggered by half a
+        // K-step (igemm2_kernel<..., STG>) — 25 % fewer staged bytes per MAC than 128 x 128.  Measured against id 7 / 9 on config 2
+        // (tools/conv_bench.py, YDL_RING=15): wins 3..8 % where one round of CTAs covers the layer and the K loop is long enough to
+        // carry the un-overlapped prologue / epilogue (256->512 k3s2 @40^2 82 -> 79 us, 512->1024 k3s2 @20^2 73 -> 69, 256->256 k3
+        // @40^2 42 -> 39, 2048->1024 @20^2 37 -> 34.5, 768->128 @80^2 54 -> 51); loses on the 9-step 160^2 layer (the persistent
+        // 128 x 128 form keeps those), with 100 tiles (512->512 k3 @20^2: 59 vs 51 us) and on the multi-class strided dgrads.
+        static const int big = getenv("YDL_RING256") ? atoi(getenv("YDL_RING256")) : 1;
+        const long b256 = (long)((M + 255) / 256) * ((Cst + 127) / 128);
+        if (big && one_class && Cst >= 128 && b256 >= 180 && b256 <= 512 && nchunks >= 96) id = 15;
         if (Cst < 128) id = ring64;
         if (forced >= 0) id = forced;
         if (id > 0) { c.ring = id; c.BM = kRingBM[id]; c.BN = kRingBN[id]; return c; }
@@ -2583,7 +2642,7 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
         nch = 1 << 30;
         for (int i = 0; i < a.ncls; ++i) nch = min(nch, a.cls_ntaps[i] * (a.Kc / (16 / (int)sizeof(T))));
     }
-    TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2, a.Kc, a.Ttot);
+    TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2, a.Kc, a.Ttot, a.ncls <= 1);
     if constexpr (sizeof(T) == 2) {
         if (c.ring && !force_bm) {
             if (path_out) { *path_out = ring_has_bnred(c.ring) ? 2 : 4; return 0; }
@@ -3711,6 +3770,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
+//              key 14 = accumulating point-wise launches: 1 (default) per-wave transposed stores also with statistics, 2 only without, 0 never
 //              key 13 = DCNv3 backward with the register window (dcnv3_bwd_win_kernel): 1 (default) on, 0 plain per-corner atomics
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
 //              key 5 = thin-input 3x3 kernel for the space-to-depth stem: 1 (default) on, 0 off (tiled kernel)
@@ -3733,6 +3793,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 10) g_resize_int = val;
     if (key == 11) g_resize_rows = val;
     if (key == 12) g_stemw = val;
+    if (key == 14) g_pw_acc_ts = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
