@@ -81,6 +81,13 @@ int ydl_conv_fwd(const ydl_conv_geom* g, int dtype, const void* x, const void* w
 /* dx (+)= conv_transpose(dy, wt).  accumulate != 0 adds into dx (gradient fan-in). */
 int ydl_conv_dgrad(const ydl_conv_geom* g, int dtype, const void* dy, const void* wt, void* dx,
                    int accumulate, void* stream);
+/* Input gradient AND weight gradient of a 1x1 / stride-1 convolution in ONE pass over dy (both are HBM-bound on large maps: dy is
+ * fetched once instead of twice; csrc/igemm.hip: pwbw_kernel).  Supported (ydl_conv_bwd_pw_supported != 0): bf16, Cin = Cout = 128,
+ * at least 131 072 pixels.  dx has its own pixel stride lddx (a channel slice of a wider gradient buffer); accumulate != 0 adds into
+ * dx; dw[Cout][g->ldw or 128] receives f32 atomic adds like ydl_conv_wgrad.  wt = [128][128] (ydl_conv_dgrad's operand). */
+int ydl_conv_bwd_pw_supported(const ydl_conv_geom* g, int dtype);
+int ydl_conv_bwd_pw(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, const void* wt, void* dx, int lddx,
+                    int accumulate, float* dw, void* stream);
 /* The input gradient with the BatchNorm backward's REDUCE pass of the layer(s) that produced the convolution's input fused into
  * its epilogue (throughput mode: replica sums, see ydl_bn_act_bwd_sums).  dx — the gradient this call completes, i.e. the `dout` of
  * those layers — is still in registers when it is stored: the epilogue reads the producers' saved pre-activations y once,

@@ -108,7 +108,7 @@ TILED = [
     ("k3_128x128_ring_small_bf16", "bf16", 3, 128, 128, 3, 1, 120, 136, ("igemm2_kernel<", "igemm2_kernel<", "", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
     ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<64>", "")),
-    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3_kernel<64>", "")),
+    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
     # one channel block: the single-patch-buffer form (four CTAs per CU)
     ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
     # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
@@ -582,3 +582,51 @@ def test_accumulating_patch_form_dgrad_through_the_c_abi(cin, cout, N, H, W, exp
     got = dx_g.float().permute(0, 3, 1, 2).cpu().double()
     assert l2_err(got, ref) < 4e-3, l2_err(got, ref)
     assert float((got - ref).abs().max()) < 1.6e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+@pytest.mark.parametrize("N,H,W,ldx,ldy,lddx,ldw", [(2, 256, 256, 128, 128, 128, 0), (3, 211, 209, 192, 128, 256, 640), (1, 363, 365, 128, 136, 128, 0)])
+def test_one_pass_pointwise_backward_through_the_c_abi(N, H, W, ldx, ldy, lddx, ldw, accumulate):
+    """ydl_conv_bwd_pw: input gradient and weight gradient of a 128 -> 128 1x1 convolution in one pass over dy (pwbw_kernel; the five
+    HBM-bound 160^2 layers of config 2) against float64 on the same bf16 operands (seg_diceloss_yolov5.py:388-409 backward): pixel counts
+    that no stage / CTA count divides, channel slices of wider buffers on every operand (x, dy, dx) and a wider weight-gradient row
+    (the column block of a commuted Concat + Conv), overwrite and gradient fan-in; dW receives atomic adds on top of its contents."""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    rs = np.random.RandomState(N * 7 + H + accumulate)
+    M = N * H * W
+    C = 128
+    x = torch.from_numpy(rs.standard_normal((M, C)).astype(np.float32)).bfloat16()
+    dy = torch.from_numpy(rs.standard_normal((M, C)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rs.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)).bfloat16()          # [co][ci]
+    dx0 = torch.from_numpy(rs.standard_normal((M, C)).astype(np.float32)).bfloat16()
+    dw0 = torch.from_numpy(rs.standard_normal((C, C)).astype(np.float32))
+    ref_dx = dy.double() @ w.double() + (dx0.double() if accumulate else 0.0)
+    ref_dw = dw0.double() + dy.double().t() @ x.double()
+    dev = torch.device("cuda")
+    canary = 7.0
+    xg = torch.full((M, ldx), canary, dtype=torch.bfloat16, device=dev); xg[:, :C] = x.to(dev)
+    dyg = torch.full((M, ldy), canary, dtype=torch.bfloat16, device=dev); dyg[:, :C] = dy.to(dev)
+    dxg = torch.full((M, lddx), canary, dtype=torch.bfloat16, device=dev); dxg[:, :C] = dx0.to(dev)
+    ldw_e = ldw or C
+    dwg = torch.full((C, ldw_e), canary, dtype=torch.float32, device=dev); dwg[:, :C] = dw0.to(dev)
+    wt = w.t().contiguous().to(dev)                                   # [ci][co]
+    g = L.ConvGeom(N, H, W, C, H, W, C, 1, 1, 0, ldx, ldy, ldw)
+    assert L.lib().ydl_conv_bwd_pw_supported(ctypes.byref(g), L.YDL_BF16) == 1
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.call("ydl_conv_bwd_pw", ctypes.byref(g), L.YDL_BF16, P(xg), P(dyg), P(wt), P(dxg), lddx, accumulate, P(dwg), st)
+    torch.cuda.synchronize()
+    assert L.last_kernel(1) == ("pwbw_kernel<128,128,acc>" if accumulate else "pwbw_kernel<128,128>") and L.last_kernel(2) == "pwbw_kernel<128,128>"
+    got_dx = dxg[:, :C].float().cpu().double()
+    assert l2_err(got_dx, ref_dx) < 4e-3, l2_err(got_dx, ref_dx)
+    assert float((got_dx - ref_dx).abs().max()) < 1.6e-2 * float(ref_dx.abs().max())
+    got_dw = dwg[:, :C].cpu().double()
+    assert l2_err(got_dw, ref_dw) < 1e-5, l2_err(got_dw, ref_dw)          # f32 accumulation of exact bf16 products
+    # nothing outside the logical channels was written
+    for buf, ld in ((dxg, lddx), (dwg, ldw_e)):
+        if ld > C:
+            assert bool((buf[:, C:].float() == canary).all())
+    # smaller maps keep the two-launch form
+    g2 = L.ConvGeom(1, 64, 64, C, 64, 64, C, 1, 1, 0, C, C, 0)
+    assert L.lib().ydl_conv_bwd_pw_supported(ctypes.byref(g2), L.YDL_BF16) == 0

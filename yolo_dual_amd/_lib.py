@@ -50,6 +50,8 @@ SIGNATURES = {
     "ydl_conv_dgrad": (_i, [_G, _i, _vp, _vp, _vp, _i, _vp]),
     "ydl_conv_dgrad_bnred_supported": (_i, [_G, _i]),
     "ydl_conv_dgrad_bnred": (_i, [_G, _i, _vp, _vp, _vp, _i, _R, _vp]),
+    "ydl_conv_bwd_pw_supported": (_i, [_G, _i]),
+    "ydl_conv_bwd_pw": (_i, [_G, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ydl_conv_wgrad": (_i, [_G, _i, _vp, _vp, _vp, _vp]),
     "ydl_conv_wgrad_ws_bytes": (_i64, [_G, _i]),
     "ydl_conv_wgrad_det": (_i, [_G, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -204,6 +206,9 @@ def profile_end():
             es = getattr(g, "_es", 2)
             wb = float(g.Cout) * g.k * g.k * g.Cin
             nbytes = (float(g.N) * g.Hi * g.Wi * g.Cin + float(g.N) * g.Ho * g.Wo * g.Cout) * es + wb * (4 if "wgrad" in name else es)
+            if getattr(g, "_both", False):
+                flops *= 2.0
+                nbytes += float(g.N) * g.Hi * g.Wi * g.Cin * es + wb * 4
         elif isinstance(g, float):
             nbytes, g = g, None
         d = {"name": name, "ms": e0.elapsed_time(e1), "flops": flops, "bytes": nbytes}
@@ -255,12 +260,14 @@ def call(name: str, *args):
     check(getattr(lib(), name)(*args), name)
     e1.record()
     g = None
-    if name in ("ydl_conv_fwd", "ydl_conv_fwd_sums", "ydl_conv_dgrad", "ydl_conv_dgrad_bnred", "ydl_conv_wgrad", "ydl_conv_wgrad_det"):
+    if name in ("ydl_conv_fwd", "ydl_conv_fwd_sums", "ydl_conv_dgrad", "ydl_conv_dgrad_bnred", "ydl_conv_wgrad", "ydl_conv_wgrad_det",
+                "ydl_conv_bwd_pw"):
         src = args[0]._obj
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
         g._es = 4 if args[1] == YDL_F32 else 2
+        g._both = name == "ydl_conv_bwd_pw"          # input AND weight gradient: twice the FLOPs, x + dy + dx + dw bytes
         g._kernel = last_kernel(1 if "dgrad" in name else 2 if "wgrad" in name else 0)
-        g._acc = int(args[5]) if "dgrad" in name else int(args[6]) if name.startswith("ydl_conv_fwd") else 0
+        g._acc = int(args[5]) if "dgrad" in name else int(args[6]) if name.startswith("ydl_conv_fwd") else int(args[7]) if g._both else 0
     elif name == "ydl_bn_act_fwd":          # algorithmic bytes: y (+ residual) read once, out written once
         es = 4 if args[0] == YDL_F32 else 2
         g = float(args[11]) * args[12] * es * (2 + (1 if args[7] else 0))

@@ -129,6 +129,15 @@ def set_bn_bwd_fuse(on: bool) -> None:
     _STATE["bn_bwd_fuse"] = bool(on)
 
 
+def fuse_pw_backward() -> bool:
+    """input + weight gradient of the HBM-bound 128 -> 128 1x1 layers in one pass over dy (ydl_conv_bwd_pw); throughput mode only"""
+    return _STATE.get("fuse_pw_backward", os.environ.get("YDL_PWBW", "1") != "0")
+
+
+def set_fuse_pw_backward(on: bool) -> None:
+    _STATE["fuse_pw_backward"] = bool(on)
+
+
 def set_dcnv3_border_rule(rule: str) -> None:
     """Which of the reference's two answers a DCNv3 sampling position EXACTLY at -1 gets (include/ydl.h: ydl_dcnv3_set_border_rule):
     "core" (default) = inside, as the pure-PyTorch core `dcnv3_core_pytorch` and the oracle have it (functions/dcnv3_func.py:148-189);

@@ -910,7 +910,35 @@ __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const
     if constexpr (STG != 0) {
         static_assert(NW == 8, "the stagger splits the CTA into waves 0-3 and 4-7");
         auto rd_step = [&](int stg) { rdfrag(stg, 0, af0, bf0); rdfrag(stg, 1, af1, bf1); };
-        auto mma_step = [&]() { mma(af0, bf0); mma(af1, bf1); };
+        // STG == 3: TIMING EXPERIMENT ONLY (VERDICT r4 item 1 ii; YDL_RING=19, never dispatched): the same 16 fragment reads feed 16
+        // v_mfma_f32_32x32x16_bf16 instead of 32 v_mfma_f32_16x16x32_bf16 — same FLOPs and LDS bytes per K-step, half the matrix
+        // instructions (8 of 32 issue cycles each instead of 8 of 16).  The operands are NOT the right fragments for that shape (the
+        // results are garbage); it answers whether the shape is worth its own fragment addressing and epilogue.
+        typedef __attribute__((ext_vector_type(16))) float f32x16;
+        f32x16 acc32[2][2];
+        if constexpr (STG == 3) {
+            static_assert(CT == 4 && PT == 4, "64 x 64 wave tiles");
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc32[c][j][e] = 0.f;
+        }
+        auto mma32 = [&](const uint4 (&af)[CT], const uint4 (&bfr)[PT]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc32[c][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[2 * h + c]),
+                                                                              __builtin_bit_cast(bf16x8, bfr[2 * h + j]), acc32[c][j], 0, 0, 0);
+        };
+        auto mma_step = [&]() {
+            if constexpr (STG == 3) { mma32(af0, bf0); mma32(af1, bf1); }
+            else { mma(af0, bf0); mma(af1, bf1); }
+        };
         if (wave < NW / 2) {
             int stg = 0;
             for (int kk = 0; kk < nk; ++kk) {
@@ -942,6 +970,14 @@ __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const
             }
             mma_step();
             if (STG == 2) __builtin_amdgcn_s_setprio(0);
+        }
+        if constexpr (STG == 3) {              // keep the 32 x 32 accumulators live through the (unchanged) epilogue
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][j][e] = acc32[c >> 1][j >> 1][((c & 1) * 2 + (j & 1)) * 4 + e];
         }
     } else {
     if (nk > 0) {
@@ -2422,8 +2458,8 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128};
 // patch-form 3x3 / stride-1 kernel (igemm2h_kernel): eligibility and launch
 static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
 static bool halo_ok(const IgemmArgs& a, int id) {
@@ -2550,6 +2586,7 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         case 16: return launch_igemm2<256, 128, 8, 4, 2, false, 1>(a, st, fam);   // the same with two stages (96 KB)
         case 17: return launch_igemm2<128, 128, 8, 4, 2, false, 2>(a, st, fam);   // staggered + s_setprio 1 for the younger half
         case 18: return launch_igemm2<256, 128, 8, 4, 3, false, 2>(a, st, fam);
+        case 19: return launch_igemm2<256, 128, 8, 4, 3, false, 3>(a, st, fam);   // timing experiment: 32x32x16 MFMAs (garbage results)
     }
     ydl_set_error("internal: unknown ring kernel id");
     return 1;
@@ -3478,6 +3515,253 @@ static int launch_wgrad3(const Wgrad2Args& a, dim3 grid, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// pwbw: input gradient AND weight gradient of a 1x1 / stride-1 convolution with 128 input and 128 output channels in ONE pass over dy
+// (round 5, VERDICT r4 item 3 ii).  Both are HBM-bound on the 160^2 maps of config 2 (the five 128 -> 128 layers: dgrad 47 us for
+// dy + dx, wgrad 58 us for x + dy, 210 MB each): run separately dy is fetched twice.  Here a persistent CTA (512 threads, one per CU)
+// walks a contiguous pixel range in 32-pixel stages; a stage's dy and x rows arrive by LDS-DMA in wgrad3's swizzled 256-byte-row
+// image (S stages, counted vmcnt), and feed
+//   * the weight gradient  dW[co][ci] += sum_p dy[p][co] x[p][ci]   — wgrad3's transposed fragment reads, waves 2 (co) x 4 (ci),
+//     accumulators live for the whole range, one f32 atomic pass at the end;
+//   * the input gradient   dx[p][ci]  = sum_co dy[p][co] wt[ci][co] — wt (32 KB) stationary in LDS, dy fragments read again from the
+//     SAME image with ds_read_b128 (conflict-free under its 32-byte-block XOR: the 16 lanes of a read group see all 8 values of
+//     f(row) in both 16-byte halves), wave w owns input channels 16 w .. 16 w + 15; results go through a double-buffered staging
+//     tile and leave as whole 256-byte pixel rows ONE STAGE LATER (after the ring's barrier — no barrier of their own), optionally
+//     added to the previous contents of dx (gradient fan-in).
+// HBM bytes: x + dy + dx once (315 MB instead of 420 MB).  Every thread issues the same memory operations per stage — two DMAs, [the
+// old dx row chunk,] one store; rows outside the range are out-of-range buffer offsets — so the in-order vmcnt arithmetic is uniform.
+// ------------------------------------------------------------------------------------------------------
+struct PwbwArgs {
+    const bf16_t* X; const bf16_t* dY; const bf16_t* Wt; bf16_t* dX; float* dW;
+    int M, ldx, ldy, lddx, ldw, chunk;
+    unsigned bytesX, bytesY, bytesDX, bytesWt;
+};
+#define PWBW_SP 32
+template <int S, bool ACC>
+__global__ __launch_bounds__(512, 2) void pwbw_kernel(const PwbwArgs p) {
+    constexpr int SP = PWBW_SP;
+    constexpr int YB = SP * 256, STAGE = 2 * YB;          // dy tile + x tile
+    constexpr int LOPS = ACC ? 4 : 3;                     // vector-memory operations per thread and stage: 2 DMAs, [old dx], store
+    constexpr int NWAIT = (S - 2) * LOPS + 1;             // younger than a stage's DMAs when its turn comes: its own store + S - 2 stages
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sWt = smem + S * STAGE;          // [128 ci][256 B of co], chunk q of row r at slot q ^ (r & 15)
+    unsigned char* const sSt = sWt + 128 * 256;           // [2][32 px][256 B of ci], chunk q of row r at slot q ^ (r & 15)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pbeg = blockIdx.x * p.chunk;
+    const int pend = min(p.M, pbeg + p.chunk);
+    u32x4 rsX, rsY, rsD, rsW;
+    {
+        const unsigned long long px = (unsigned long long)p.X, py = (unsigned long long)p.dY, pd = (unsigned long long)p.dX,
+                                 pw = (unsigned long long)p.Wt;
+        rsX = u32x4{(unsigned)px, (unsigned)(px >> 32) & 0xffffu, p.bytesX, 0x00020000u};
+        rsY = u32x4{(unsigned)py, (unsigned)(py >> 32) & 0xffffu, p.bytesY, 0x00020000u};
+        rsD = u32x4{(unsigned)pd, (unsigned)(pd >> 32) & 0xffffu, p.bytesDX, 0x00020000u};
+        rsW = u32x4{(unsigned)pw, (unsigned)(pw >> 32) & 0xffffu, p.bytesWt, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // DMA slot of this thread: row r of the 32-row tile, 16-byte slot q; it fetches the logical chunk the swizzle puts there
+    const int r = t >> 4, q = t & 15;
+    const unsigned qlog = (unsigned)((((q >> 1) ^ w3f<256>(r)) << 1) | (q & 1)) << 4;
+    const unsigned wave_lds = lds0 + (unsigned)wave * 1024u;
+    auto issue = [&](int p0, int buf) {
+        const int m = p0 + r;
+        const bool ok = m < pend;
+        lds_dma16(rsY, wave_lds + (unsigned)buf * STAGE, ok ? (unsigned)m * (unsigned)(p.ldy * 2) + qlog : 0xFFFFFFFFu);
+        lds_dma16(rsX, wave_lds + (unsigned)buf * STAGE + YB, ok ? (unsigned)m * (unsigned)(p.ldx * 2) + qlog : 0xFFFFFFFFu);
+    };
+    // the old contents of this thread's 16 bytes of dx (row r, chunk q of the stage that began at p0); issued from asm so that the
+    // compiler's own wait-count insertion does not drain the ring for it (it counts only the operations it knows)
+    u32x4 old = u32x4{0u, 0u, 0u, 0u};
+    auto dx_off = [&](int p0) -> unsigned {
+        const int m = p0 + r;
+        return (m >= pbeg && m < pend) ? (unsigned)m * (unsigned)(p.lddx * 2) + (unsigned)(q << 4) : 0xFFFFFFFFu;
+    };
+    auto load_old = [&](int p0) {
+        if constexpr (ACC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(old) : "v"(dx_off(p0)), "s"(rsD) : "memory");
+    };
+    // weights: 4 passes of 32 rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = r + 32 * i;
+        lds_dma16(rsW, lds0 + (unsigned)(S * STAGE) + (unsigned)i * 8192u + (unsigned)wave * 1024u,
+                  (unsigned)row * 256u + (unsigned)((q ^ (row & 15)) << 4));
+    }
+    // prologue: S - 1 stages, each followed by the same dummy operations a loop iteration issues behind its DMAs
+#pragma unroll
+    for (int u = 0; u < S - 1; ++u) {
+        if constexpr (ACC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(old) : "v"(0xFFFFFFFFu), "s"(rsD) : "memory");
+        issue(pbeg + u * SP, u);
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(old), "v"(0xFFFFFFFFu), "s"(rsD) : "memory");
+    }
+
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    // ---- weight-gradient fragments (wgrad3's map): waves 2 (co) x 4 (ci), 64 x 32 per wave
+    const int wi = wave >> 2, wj = wave & 3;
+    const int g4 = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    f32x4 accw[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto trfrag = [&](const unsigned char* tile, int col) -> uint4 {
+        const int row = g4 * 8 + lq;
+        const unsigned char* lo_p = tile + w3sw<256>(row, col * 2);
+        const unsigned char* hi_p = tile + w3sw<256>(row + 4, col * 2);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
+        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
+    // ---- input-gradient fragments: wave w owns ci 16 w .. 16 w + 15 (MFMA A rows), all 32 pixels (two B tiles)
+    const unsigned char* const wrow = sWt + (wave * 16 + lrow) * 256;
+    auto compute = [&](int buf, int sbuf) {
+        const unsigned char* by = smem + buf * STAGE;
+        const unsigned char* bx = by + YB;
+        {
+            uint4 af[4], bfv[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = trfrag(by, wi * 64 + a * 16 + lp * 4);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bfv[b] = trfrag(bx, wj * 32 + b * 16 + lp * 4);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) Mma<bf16_t>::run(af[a], bfv[b], accw[a][b]);
+        }
+        f32x4 accd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ks * 4 + lgrp;                                 // 16-byte chunk of the 128 output channels (K)
+            const uint4 a = *(const uint4*)(wrow + ((ch ^ lrow) << 4));
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const uint4 b = *(const uint4*)(by + w3sw<256>(pt * 16 + lrow, ch * 16));
+                Mma<bf16_t>::run(a, b, accd[pt]);
+            }
+        }
+        // lane: 4 consecutive input channels (16 w + 4 lgrp ..) of pixel pt * 16 + lrow
+        unsigned char* const st = sSt + sbuf * (SP * 256);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int px = pt * 16 + lrow;
+            const int chq = wave * 2 + (lgrp >> 1);
+            uint2 u;
+            u.x = (uint32_t)f2bf(accd[pt][0]) | ((uint32_t)f2bf(accd[pt][1]) << 16);
+            u.y = (uint32_t)f2bf(accd[pt][2]) | ((uint32_t)f2bf(accd[pt][3]) << 16);
+            *(uint2*)(st + px * 256 + ((chq ^ (px & 15)) << 4) + ((lgrp & 1) << 3)) = u;
+        }
+    };
+    // the rows of the stage that began at p0 leave the staging tile: 16 bytes per thread, a whole pixel row per 16 lanes
+    auto store_rows = [&](int p0, int sbuf) {
+        const unsigned char* const st = sSt + sbuf * (SP * 256);
+        uint4 v = *(const uint4*)(st + r * 256 + ((q ^ (r & 15)) << 4));
+        if constexpr (ACC) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(old) : "n"(2) : "memory");      // older than this stage's two DMAs only
+            float a8[8], o8[8];
+            unpack16<bf16_t>(v, a8);
+            unpack16<bf16_t>(make_uint4(old.x, old.y, old.z, old.w), o8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[e] += o8[e];
+            v = pack16<bf16_t>(a8);
+        }
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u32x4{v.x, v.y, v.z, v.w}), "v"(dx_off(p0)), "s"(rsD) : "memory");
+    };
+
+    int buf = 0, nxt = S - 1, k = 0;
+    for (int p0 = pbeg; p0 < pend; p0 += SP, ++k) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // own staging writes / fragment reads of the previous stage are done
+        wait_vm_barrier<NWAIT>();
+        load_old(p0 - SP);                                       // (stage -1: out of range)
+        issue(p0 + (S - 1) * SP, nxt);
+        store_rows(p0 - SP, (k + 1) & 1);
+        compute(buf, k & 1);
+        buf = buf + 1 == S ? 0 : buf + 1;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vm_barrier<0>();
+    if (k > 0) {
+        load_old(pbeg + (k - 1) * SP);
+        if constexpr (ACC) asm volatile("s_nop 0" ::: "memory");
+        // (no DMA follows: the wait inside store_rows must see the load as the only outstanding operation)
+        if constexpr (ACC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(old)::"memory");
+        const unsigned char* const st = sSt + ((k - 1) & 1) * (SP * 256);
+        uint4 v = *(const uint4*)(st + r * 256 + ((q ^ (r & 15)) << 4));
+        if constexpr (ACC) {
+            float a8[8], o8[8];
+            unpack16<bf16_t>(v, a8);
+            unpack16<bf16_t>(make_uint4(old.x, old.y, old.z, old.w), o8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[e] += o8[e];
+            v = pack16<bf16_t>(a8);
+        }
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u32x4{v.x, v.y, v.z, v.w}), "v"(dx_off(pbeg + (k - 1) * SP)), "s"(rsD) : "memory");
+    }
+    // weight gradient: one atomic pass over the CTA's 128 x 128 tile
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = wj * 32 + b * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = wi * 64 + a * 16 + (lane >> 4) * 4 + e;
+                atomicAdd(p.dW + (size_t)co * p.ldw + j, accw[a][b][e]);
+            }
+        }
+}
+
+static int g_pwbw = 1;          // ydl_debug_set key 15
+static bool pwbw_ok(const ydl_conv_geom* g, int dtype) {
+    static const int env = getenv("YDL_PWBW") ? atoi(getenv("YDL_PWBW")) : 1;
+    if (!env || !g_pwbw || g == nullptr || dtype != YDL_BF16) return false;
+    if (g->k != 1 || g->s != 1 || g->p != 0 || g->Cin != 128 || g->Cout != 128) return false;
+    if (g->Hi != g->Ho || g->Wi != g->Wo) return false;
+    const long long M = (long long)g->N * g->Ho * g->Wo;
+    if (M < 131072 || M >= (1ll << 30)) return false;                  // HBM-bound sizes only: the deep layers keep their MFMA kernels
+    if (g->ldx < 128 || g->ldy < 128 || (g->ldx & 7) || (g->ldy & 7)) return false;
+    if ((unsigned long long)M * (unsigned long long)max(g->ldx, g->ldy) * 2ull >= 0xFFFFFFF0ull) return false;
+    return true;
+}
+extern "C" int ydl_conv_bwd_pw_supported(const ydl_conv_geom* g, int dtype) { return pwbw_ok(g, dtype) ? 1 : 0; }
+
+extern "C" int ydl_conv_bwd_pw(const ydl_conv_geom* g, int dtype, const void* x, const void* dy, const void* wt, void* dx, int lddx,
+                               int accumulate, float* dw, void* stream) {
+    YDL_CHECK(pwbw_ok(g, dtype), "ydl_conv_bwd_pw: geometry not supported (query ydl_conv_bwd_pw_supported)");
+    YDL_CHECK(x && dy && wt && dx && dw, "null pointer");
+    YDL_CHECK(aligned16(x) && aligned16(dy) && aligned16(wt) && aligned16(dx), "pointers must be 16-byte aligned");
+    YDL_CHECK(lddx >= 128 && (lddx & 7) == 0, "dx pixel stride");
+    const int M = g->N * g->Ho * g->Wo;
+    YDL_CHECK((unsigned long long)M * (unsigned long long)lddx * 2ull < 0xFFFFFFF0ull, "dx larger than 4 GiB");
+    PwbwArgs a{};
+    a.X = (const bf16_t*)x; a.dY = (const bf16_t*)dy; a.Wt = (const bf16_t*)wt; a.dX = (bf16_t*)dx; a.dW = dw;
+    a.M = M; a.ldx = g->ldx; a.ldy = g->ldy; a.lddx = lddx; a.ldw = g->ldw ? g->ldw : 128;
+    int ctas = ydl_device_cus();
+    int chunk = (M + ctas - 1) / ctas;
+    chunk = (chunk + PWBW_SP - 1) / PWBW_SP * PWBW_SP;
+    ctas = (M + chunk - 1) / chunk;
+    a.chunk = chunk;
+    a.bytesX = (unsigned)((unsigned long long)(M - 1) * g->ldx * 2ull + 256ull);
+    a.bytesY = (unsigned)((unsigned long long)(M - 1) * g->ldy * 2ull + 256ull);
+    a.bytesDX = (unsigned)((unsigned long long)(M - 1) * lddx * 2ull + 256ull);
+    a.bytesWt = 128u * 256u;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int S = 5;
+    const size_t smem = (size_t)S * 2 * PWBW_SP * 256 + 128 * 256 + 2 * PWBW_SP * 256;
+    ydl_note_kernel(1, accumulate ? "pwbw_kernel<128,128,acc>" : "pwbw_kernel<128,128>");
+    ydl_note_kernel(2, "pwbw_kernel<128,128>");
+    if (accumulate) {
+        YDL_SET_MAX_LDS((pwbw_kernel<S, true>), smem);
+        pwbw_kernel<S, true><<<ctas, 512, smem, st>>>(a);
+    } else {
+        YDL_SET_MAX_LDS((pwbw_kernel<S, false>), smem);
+        pwbw_kernel<S, false><<<ctas, 512, smem, st>>>(a);
+    }
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Weight gradient of the space-to-depth stem (3x3, stride 1, pad 1, 16 stored input channels -> 64 output channels; BASELINE
 // config 2: 16 x 320 x 320 pixels).  K = 9 taps x 16 channels = 144 columns: the tiled kernel above needs TWO 128-column tiles
 // (the second one 16 columns wide: every dY byte is fetched twice, half of the MFMAs multiply zeros) and gathers the nine taps of
@@ -3770,6 +4054,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
+//              key 15 = one-pass input + weight gradient of the 128 -> 128 1x1 layers (pwbw_kernel): 1 (default) on, 0 two launches
 //              key 14 = accumulating point-wise launches: 1 (default) per-wave transposed stores also with statistics, 2 only without, 0 never
 //              key 13 = DCNv3 backward with the register window (dcnv3_bwd_win_kernel): 1 (default) on, 0 plain per-corner atomics
 //              key 6 = persistent form of the two-stage ring kernel (igemm2p_kernel): 1 (default) on, 0 off
@@ -3794,6 +4079,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 11) g_resize_rows = val;
     if (key == 12) g_stemw = val;
     if (key == 14) g_pw_acc_ts = val;
+    if (key == 15) g_pwbw = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {

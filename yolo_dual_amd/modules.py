@@ -160,8 +160,15 @@ class YdlModule(nn.Module):
 # ----------------------------------------------------------------------------------------------------------
 # Conv = Conv2d(bias=False) -> BatchNorm2d -> SiLU
 # ----------------------------------------------------------------------------------------------------------
-def _launch_wgrad(tape: Tape, gp, x_ptr, dy_ptr, dw_ptr, st) -> None:
-    """dW += dy^T * im2col(x): f32 atomics (throughput mode) or the deterministic slab form (parity mode / config)"""
+def _launch_wgrad(tape: Tape, gp, x_ptr, dy_ptr, dw_ptr, st, fuse=None) -> bool:
+    """dW += dy^T * im2col(x): f32 atomics (throughput mode) or the deterministic slab form (parity mode / config).
+    ``fuse`` = (wt_ptr, dx_ptr, lddx, accumulate) of the SAME layer's input gradient: where the one-pass kernel applies (the
+    HBM-bound 128 -> 128 1x1 layers, ydl_conv_bwd_pw) both gradients come from one launch and the call returns True."""
+    if (fuse is not None and not config.deterministic(tape.dname) and config.fuse_pw_backward()
+            and L.lib().ydl_conv_bwd_pw_supported(gp, tape.dt)):
+        wt_ptr, dx_ptr, lddx, acc = fuse
+        L.call("ydl_conv_bwd_pw", gp, tape.dt, x_ptr, dy_ptr, wt_ptr, dx_ptr, lddx, acc, dw_ptr, st)
+        return True
     if config.deterministic(tape.dname):
         nbytes = L.lib().ydl_conv_wgrad_ws_bytes(gp, tape.dt)
         ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=tape.device)
@@ -169,6 +176,7 @@ def _launch_wgrad(tape: Tape, gp, x_ptr, dy_ptr, dw_ptr, st) -> None:
         tape._keep.append(ws)          # may be consumed on the side stream: lives until the streams are joined
     else:
         L.call("ydl_conv_wgrad", gp, tape.dt, x_ptr, dy_ptr, dw_ptr, st)
+    return False
 
 
 class _BNHolder(nn.BatchNorm2d):
@@ -309,19 +317,20 @@ class Conv(YdlModule):
         """the weight gradient can be written per input-channel block (``wgrad(col0=...)``): dense KRSC storage"""
         return self.c1 % 8 == 0 and self.conv.weight.detach().permute(0, 2, 3, 1).is_contiguous()
 
-    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True) -> None:
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True, fuse=None) -> bool:
         """``col0``: first input channel of the block this call covers (gp.ldw = total padded Cin then); ``final``: the
-        last launch writing this parameter's gradient (only then may the data-parallel hook see it)"""
+        last launch writing this parameter's gradient (only then may the data-parallel hook see it); ``fuse``: see
+        ``_launch_wgrad`` — returns True when the input gradient was produced by the same launch"""
         p = self.conv.weight
         g = self._grad_of(p)
         gk = g.permute(0, 2, 3, 1)
         kk = self.k * self.k
         cin_p = round_up(self.c1, 8)
         if cin_p == self.c1 and gk.is_contiguous():
-            _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
+            done = _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st, fuse)
             if final:
                 config.mark_touched(p)
-            return
+            return done
         assert col0 == 0 and final
         tmp = zero_(torch.empty((self.c2, kk, cin_p), dtype=torch.float32, device=g.device), st)
         _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), _p(tmp), st)
@@ -330,6 +339,7 @@ class Conv(YdlModule):
         else:                                           # exotic grad layout: let torch place it (cold path)
             g.add_(tmp[:, :, :self.c1].view(self.c2, self.k, self.k, self.c1).permute(0, 3, 1, 2))
         config.mark_touched(p)
+        return False
 
     # -- forward ----------------------------------------------------------------------------------------
     # -- depth-wise variant (weight [C,1,k,k]: the KRSC physical layout is [C][k*k]) -------------------------
@@ -558,13 +568,14 @@ class _FusedPair:
     def splittable(self) -> bool:
         return self.c1 % 8 == 0
 
-    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True) -> None:
+    def wgrad(self, tape: Tape, gp, x: Var, dy: Var, st, col0: int = 0, final: bool = True, fuse=None) -> bool:
         p1, p2 = self._grads("w")
         gk = p1.grad.permute(0, 2, 3, 1)
-        _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st)
+        done = _launch_wgrad(tape, gp, _p(x.t), _p(dy.t), ctypes.c_void_p(gk.data_ptr() + 4 * col0), st, fuse)
         if final:
             config.mark_touched(p1)
             config.mark_touched(p2)
+        return done
 
 
 class _FusedBN:

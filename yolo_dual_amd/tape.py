@@ -741,6 +741,15 @@ class Tape:
             if subs is not None:
                 self._bw_split(m, subs, dy, wt, Cout_p, Ho, Wo, st2)
                 return
+            if (train_w and x.need and not _cfg.bn_bwd_fuse() and _cfg.fuse_pw_backward() and not _cfg.deterministic(self.dname)
+                    and L.lib().ydl_conv_bwd_pw_supported(gp, self.dt)):
+                # HBM-bound 1x1 layer: input and weight gradient in ONE pass over dy, on the main stream (ydl_conv_bwd_pw)
+                gx, acc = self.grad_target(x)
+                if m.wgrad(self, gp, x, dy, st2, fuse=(_p(wt), _p(gx), x.ld, acc)):
+                    _keep = (geom,)
+                    return
+                L.call("ydl_conv_dgrad", gp, self.dt, _p(dy.t), _p(wt), _p(gx), acc, st2)     # (the weight gradient ran alone)
+                return
             if not train_w:
                 pass                                       # frozen weight: no weight-gradient launch, never marked touched
             elif x.need and _cfg.overlap_wgrad():
@@ -794,6 +803,26 @@ class Tape:
                 gv = L.ConvGeom(v.N, v.H, v.W, v.C, v.H, v.W, dy.C, 1, 1, 0, v.ld, d.ld, gv.ldw)
             jobs.append((v, c0_, gv, d))
         overlap = _cfg.overlap_wgrad() and any(v.need for (v, _c, _g, _d) in jobs)
+        fused = set()
+        if (m.trainable()[0] and not _cfg.bn_bwd_fuse() and _cfg.fuse_pw_backward() and not _cfg.deterministic(self.dname)):
+            # sources whose column block is an HBM-bound 128 -> 128 layer of its own: both gradients in one pass (ydl_conv_bwd_pw)
+            todo = [i for i, (v, c0_, gv, d) in enumerate(jobs)
+                    if v.need and L.lib().ydl_conv_bwd_pw_supported(ctypes.byref(gv), self.dt)]
+            rest = [i for i in range(len(jobs)) if i not in todo]
+            for i in todo:
+                v, c0_, gv, d = jobs[i]
+                gx, acc = self.grad_target(v)
+                wtv = ctypes.c_void_p(wt.data_ptr() + c0_ * Cout_p * es)
+                if m.wgrad(self, ctypes.byref(gv), v, d, st2, col0=c0_, final=(not rest and i == todo[-1]), fuse=(wtv, _p(gx), v.ld, acc)):
+                    fused.add(i)
+                else:
+                    L.call("ydl_conv_dgrad", ctypes.byref(gv), self.dt, _p(d.t), wtv, _p(gx), acc, st2)
+                    fused.add(i)
+            if fused:
+                self._keep.append(tuple(g for (_v, _c, g, _d) in jobs))
+                jobs = [jobs[i] for i in rest]
+                if not jobs:
+                    return
         if not m.trainable()[0]:
             pass                                           # frozen weight
         elif overlap:
