@@ -207,21 +207,25 @@ def test_dcnv3_backward_stays_inside_grad_input(sigma):
     canary = 12345.678
     res = {}
     try:
-        for win in (1, 0):
-            L.debug_set(13, win)
+        # 2: the tile kernel (scatter as S x grad_output on the MFMA, round 5); 1: the register-window kernel; 0: plain per-corner atomics
+        for mode in (2, 1, 0):
+            L.debug_set(16, 1 if mode == 2 else 0)
+            L.debug_set(13, 1 if mode >= 1 else 0)
             big = torch.full((margin + n_el + margin,), canary, dtype=torch.float32, device="cuda")
             gin = big[margin:margin + n_el].view(N, H, W, C)
             gin.zero_()
             goff, gmsk = _dcn_bwd_raw(L.YDL_BF16, inp, off, msk, go, gin, G, Gc)
             assert bool((big[:margin] == canary).all()) and bool((big[margin + n_el:] == canary).all()), \
-                f"grad_input's margins were written (window kernel {win})"
-            res[win] = (gin.clone(), goff, gmsk)
+                f"grad_input's margins were written (backward form {mode})"
+            res[mode] = (gin.clone(), goff, gmsk)
     finally:
         L.debug_set(13, 1)
+        L.debug_set(16, 1)
     scale = float(res[0][0].abs().max())
-    assert float((res[1][0] - res[0][0]).abs().max()) <= 1e-4 * scale            # same products, different summation order
-    assert torch.equal(res[1][1], res[0][1]) or float((res[1][1] - res[0][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max())
-    assert float((res[1][2] - res[0][2]).abs().max()) <= 1e-5 * float(res[0][2].abs().max())
+    for mode in (2, 1):
+        assert float((res[mode][0] - res[0][0]).abs().max()) <= 1e-4 * scale, mode            # same products, different summation order
+        assert float((res[mode][1] - res[0][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max()), mode
+        assert float((res[mode][2] - res[0][2]).abs().max()) <= 1e-5 * float(res[0][2].abs().max()), mode
 
 
 @pytest.mark.parametrize("Gc", [16, 64])          # 16: the plain kernel (several items per wave); 64: the register-window kernel
@@ -233,12 +237,12 @@ def test_dcnv3_border_rule_pins_both_conventions(Gc):
     import yolo_dual_amd as ydl
     from oracle import ref_cpu as R
     from yolo_dual_amd import _lib as L
-    N, H, W, G = 2, 6, 7, 2
+    N, H, W, G = 2, 9, 10, 2          # (>= 8 x 8 with 64 channels per group: the tile backward, partial tiles included)
     C = G * Gc
     g = torch.Generator().manual_seed(3)
     inp = torch.randn(N, H, W, C, generator=g)
     off = torch.zeros(N, H, W, G * 18)
-    off[:, 2:4, 2:5] = torch.randn(N, 2, 3, G * 18, generator=g) * 0.3          # interior pixels get real offsets
+    off[:, 3:6, 3:7] = torch.randn(N, 3, 4, G * 18, generator=g) * 0.3          # interior pixels get real offsets
     msk = torch.softmax(torch.randn(N, H, W, G, 9, generator=g), -1).reshape(N, H, W, G * 9)
     go = torch.randn(N, H, W, C, generator=g)
     ri, ro, rm = (t.clone().requires_grad_(True) for t in (inp, off, msk))
@@ -273,3 +277,32 @@ def test_dcnv3_border_rule_pins_both_conventions(Gc):
     assert torch.allclose(out["cuh"][1][~edge], ro.grad.view(N, H, W, G, P, 2)[~edge], **tol(ro.grad))
     assert torch.allclose(out["cuh"][2][~edge], rm.grad.view(N, H, W, G, P)[~edge], **tol(rm.grad))
     assert torch.allclose(out["cuh"][0], ri.grad, **tol(ri.grad))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_dcnv3_tile_backward_against_the_oracle(dtype):
+    """dcnv3_bwd_tile_kernel (8 x 8 pixel tiles, grad_input = S x grad_output on the f32 MFMA, 18 x 18 cell windows) against the CPU
+    oracle's autograd (functions/dcnv3_func.py:148-189) with offsets of sigma = 2.5 px: corners inside the window, beyond it (direct
+    atomics) and outside the image, image sizes that leave partial tiles, two images and three groups."""
+    import ctypes
+    from oracle import ref_cpu as R
+    from yolo_dual_amd import _lib as L
+    N, H, W, G, Gc = 2, 21, 19, 3, 64
+    C = G * Gc
+    g = torch.Generator().manual_seed(9)
+    inp = torch.randn(N, H, W, C, generator=g)
+    off = torch.randn(N, H, W, G * 18, generator=g) * 2.5
+    msk = torch.softmax(torch.randn(N, H, W, G, 9, generator=g), -1).reshape(N, H, W, G * 9)
+    go = torch.randn(N, H, W, C, generator=g)
+    if dtype == "bf16":
+        inp, off, msk, go = (t.bfloat16().float() for t in (inp, off, msk, go))
+    ri, ro, rm = (t.clone().requires_grad_(True) for t in (inp, off, msk))
+    (R.dcnv3_core(ri, ro, rm, 3, 3, 1, 1, 1, 1, 1, 1, G, Gc, 1.0) * go).sum().backward()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    dt = L.YDL_BF16 if dtype == "bf16" else L.YDL_F32
+    gin = torch.zeros(N, H, W, C, device="cuda")
+    goff, gmsk = _dcn_bwd_raw(dt, inp.cuda().to(tdt), off.cuda().to(tdt), msk.cuda().to(tdt), go.cuda().to(tdt), gin, G, Gc)
+    tol = lambda r: dict(rtol=2e-3, atol=max(1e-5, 5e-5 * float(r.abs().max())))
+    assert torch.allclose(gin.cpu(), ri.grad, **tol(ri.grad)), float((gin.cpu() - ri.grad).abs().max())
+    assert torch.allclose(goff.cpu(), ro.grad, **tol(ro.grad)), float((goff.cpu() - ro.grad).abs().max())
+    assert torch.allclose(gmsk.cpu(), rm.grad, **tol(rm.grad)), float((gmsk.cpu() - rm.grad).abs().max())

@@ -172,12 +172,23 @@ def test_pointwise_streaming_kernel_against_oracle(case):
     _check(got, ref, mode, tag)
 
 
-@pytest.mark.parametrize("c1,c2,k,expk", [(128, 128, 1, "wgrad3_kernel<128>"), (128, 64, 3, "wgrad3_kernel<64>"),
-                                          (64, 128, 3, "wgrad3_kernel<128>")])
+@pytest.mark.parametrize("c1,c2,k,expk", [(128, 128, 1, "pwbw_kernel<128,128>"), (128, 64, 3, "wgrad3_kernel<64>"),
+                                          (64, 128, 3, "wgrad3_kernel<128>"), (128, 128, 1, "wgrad3_kernel<128>")])
 def test_wgrad2_pipelined_kernel_against_oracle(c1, c2, k, expk):
-    """bf16, M = 8*160*160 = 204 800 >= 200 000 pixels: the 128-wide weight-gradient kernel (LDS-DMA feed, wgrad3_kernel)"""
-    got, ref, kern = _case("bf16", 8, c1, c2, k, 1, 160, 160)
+    """bf16, M = 8*160*160 = 204 800 >= 200 000 pixels: the 128-wide weight-gradient kernel (LDS-DMA feed, wgrad3_kernel); the
+    128 -> 128 1x1 layer as the model runs it — input and weight gradient from ONE pass over dy (pwbw_kernel, round 5) — and with
+    that switched off (ydl_debug_set key 15): the separate weight-gradient launch"""
+    from yolo_dual_amd import _lib as L
+    two_launches = k == 1 and expk.startswith("wgrad3")
+    if two_launches:
+        L.debug_set(15, 0)
+    try:
+        got, ref, kern = _case("bf16", 8, c1, c2, k, 1, 160, 160)
+    finally:
+        L.debug_set(15, 1)
     assert kern["wgrad"] == expk, kern
+    if expk.startswith("pwbw"):
+        assert kern["dgrad"] == expk, kern
     _check(got, ref, "bf16", expk)
 
 

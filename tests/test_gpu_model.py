@@ -157,9 +157,24 @@ def test_bf16_tracks_f32():
     x-hat component of dz, the remainder is small against the bf16-rounded operands it is computed from.)"""
     import yolo_dual_amd as ydl
     from tests.util import l2_err
+    from yolo_dual_amd import config
     res = {}
-    for mode in ("f32", "bf16"):
-        ydl.set_compute_dtype(mode)
+    planes = {}
+    # third leg (round 5): the bf16 run again, but its SPPF max-pool BACKWARD routes by the f32 run's arg-max planes — the test of the
+    # attribution above: if the backbone's 0.24-0.32 is re-routed arg-max elements, it must fall to the head's level with them forced
+    for mode in ("f32", "bf16", "bf16_forced"):
+        ydl.set_compute_dtype("bf16" if mode.startswith("bf16") else "f32")
+        if mode == "f32":
+            config.set_sppf_argmax_hook(lambda idx: planes.setdefault("f32", [t.clone() for t in idx]))
+        elif mode == "bf16_forced":
+            def force(idx):
+                assert all(a.shape == b.shape for a, b in zip(idx, planes["f32"]))
+                planes["changed"] = [float((a != b).float().mean()) for a, b in zip(idx, planes["f32"])]
+                for a, b in zip(idx, planes["f32"]):
+                    a.copy_(b)
+            config.set_sppf_argmax_hook(force)
+        else:
+            config.set_sppf_argmax_hook(None)
         m = ydl.YOLOv5Seg(_cfg("yolov5_seg.yaml", {"C3_DCN": "C3"}))
         m.img_size = [256, 256]
         sd = m.state_dict()
@@ -175,8 +190,14 @@ def test_bf16_tracks_f32():
         total.backward()
         res[mode] = (out.detach().float().cpu(), items,
                      {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if getattr(p, "_ydl_touched", False)})
+    config.set_sppf_argmax_hook(None)
     ydl.set_compute_dtype("bf16")
     assert sorted(res["bf16"][2]) == sorted(res["f32"][2])
+    errs_forced = {k: l2_err(res["bf16_forced"][2][k], res["f32"][2][k]) for k in res["f32"][2]}
+    back_forced = [e for k, e in errs_forced.items() if k.startswith("backbone.") and not k.startswith("backbone.9.cv2.")]
+    print(f"[bf16 vs f32] arg-max elements that differ per pool stage: {planes['changed']}; backbone gradient error with the f32 "
+          f"planes forced: median {float(np.median(back_forced)):.3f}, worst {max(back_forced):.3f}")
+    assert max(back_forced) < 0.15, sorted(((e, k) for k, e in errs_forced.items() if k.startswith("backbone.")), reverse=True)[:5]
     assert l2_err(res["bf16"][0], res["f32"][0]) < 0.09                           # measured 0.062
     assert abs(res["bf16"][1][0] - res["f32"][1][0]) <= 1e-3 * abs(res["f32"][1][0])      # measured 1e-5
     errs = {k: l2_err(res["bf16"][2][k], res["f32"][2][k]) for k in res["f32"][2]}
@@ -186,7 +207,7 @@ def test_bf16_tracks_f32():
             return 0.09                                                            # measured <= 0.055
         if k.startswith("head.") or k.startswith("backbone.9.cv2."):
             return 0.2                                                             # measured <= 0.133
-        return 0.45                                                                # behind the max-pools: measured <= 0.32
+        return 0.42                                                                # behind the max-pools: 1.3 x the measured 0.32
     bad = {k: (e, bound(k)) for k, e in errs.items() if e > bound(k)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6]
     back = [e for k, e in errs.items() if k.startswith("backbone.") and not k.startswith("backbone.9.cv2.")]

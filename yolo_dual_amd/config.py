@@ -129,6 +129,16 @@ def set_bn_bwd_fuse(on: bool) -> None:
     _STATE["bn_bwd_fuse"] = bool(on)
 
 
+def sppf_argmax_hook():
+    """test instrument (tests/test_gpu_model.py::test_bf16_tracks_f32): a callable that receives the three uint8 arg-max planes of an
+    SPPF pool chain right after the forward launch and may copy other planes into them; None (default) = nothing is called"""
+    return _STATE.get("sppf_argmax_hook")
+
+
+def set_sppf_argmax_hook(fn) -> None:
+    _STATE["sppf_argmax_hook"] = fn
+
+
 def fuse_pw_backward() -> bool:
     """input + weight gradient of the HBM-bound 128 -> 128 1x1 layers in one pass over dy (ydl_conv_bwd_pw); throughput mode only"""
     return _STATE.get("fuse_pw_backward", os.environ.get("YDL_PWBW", "1") != "0")

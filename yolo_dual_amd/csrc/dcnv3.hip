@@ -45,9 +45,10 @@ struct DcnArgs {
 
 static int g_dcn_border_rule = 0;
 static int g_dcn_win = 1;          // ydl_debug_set key 13 (YDL_DCN_NOWIN=1 at start-up switches the window backward off)
+static int g_dcn_tile = 1;         // ydl_debug_set key 16: 1 (default) tile backward (S x grad_output on the MFMA) where it applies, 0 off
 extern "C" void ydl_dcnv3_set_border_rule(int rule) { g_dcn_border_rule = rule ? 1 : 0; }
 extern "C" int ydl_dcnv3_get_border_rule(void) { return g_dcn_border_rule; }
-void ydl_dcn_debug_set(int key, int val) { if (key == 13) g_dcn_win = val; }
+void ydl_dcn_debug_set(int key, int val) { if (key == 13) g_dcn_win = val; if (key == 16) g_dcn_tile = val; }
 
 // inside test of a sampling position: lower edge by the selected rule, upper edge exclusive in both conventions
 __device__ __forceinline__ bool dcn_inside(float lh_, float lw_, int H, int W, int strict) {
@@ -275,6 +276,169 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Backward for 3 x 3 / stride 1 / dilation 1 / offset_scale 1 with 64 channels per group, round 5: the grad_input scatter as a MATRIX
+// PRODUCT.  What every corner adds is (bilinear weight x mask) — one scalar per (output pixel, corner), the same for all channels —
+// times grad_output[pixel][c]:      grad_input[cell][c] = sum_pixels S[cell][pixel] * grad_output[pixel][c].
+// A CTA owns an 8 x 8 tile of output pixels of one (image, group) and the 18 x 18 window of input cells that sampling offsets
+// below 4 pixels can reach (T_R = 4: 324 cells).  Phase 1, a wave per pixel as in the kernels above (lanes = channels: gathers of the
+// four corners, grad_offset / grad_mask by DPP wave totals): the corner scalars do NOT go to memory — the wave keeps its pixel's
+// column of S in registers (cell q in lane q & 63, slot q >> 6; a uniform cell index, one lane adds) and writes it once, together
+// with its grad_output row (f32), to LDS: no atomics, no zero fill, every (pixel, cell) is written.  Phase 2: S x GO on the f32 MFMA
+// (v_mfma_f32_16x16x4_f32: exact f32 products, 21 x 4 tiles x 16 k-steps per CTA), transposed through the (now free) S area into
+// [cell][64 channels] rows, and each in-image, non-zero row leaves with ONE 256-byte atomic instruction: 83 KB of atomics per 64
+// pixels instead of 590 KB, whatever the offsets are.  Corners beyond the window (|offset| >= 4 px) keep their direct atomics.
+// Reference arithmetic: dcnv3_im2col_cuda.cuh:82-147 (same products; the sum over pixels is formed in the MFMA's order).
+// ------------------------------------------------------------------------------------------------------
+#define T_R 4
+#define T_WIN (10 + 2 * T_R)                 // window edge: taps th-p .. th+9-p, +-R, +1 for the upper bilinear corner
+#define T_CELLS (T_WIN * T_WIN)              // 324
+#define T_CPAD ((T_CELLS + 15) / 16 * 16)    // 336: whole 16-row MFMA tiles
+#define T_SLOTS ((T_CPAD + 63) / 64)         // 6 column registers per lane
+#define T_GOLD 80                            // GO row stride (floats): 16 banks per row => conflict-free 16x16x4 B-operand reads
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__global__ __launch_bounds__(1024) void dcnv3_bwd_tile_kernel(const DcnArgs a, int tiles_w, int tiles_hw) {
+    extern __shared__ __attribute__((aligned(16))) float slds[];
+    float* const sS = slds;                              // [64 pixels][T_CPAD cells]  (S transposed: a pixel's column is contiguous)
+    float* const sGO = slds + 64 * T_CPAD;               // [64 pixels][T_GOLD]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 16 waves, 4 pixels each
+    constexpr int P = 9;
+    const int C = a.G * a.Gc;
+    int b = blockIdx.x;
+    const int g = b % a.G; b /= a.G;
+    const int tl = b % tiles_hw;
+    const int n = b / tiles_hw;
+    const int th = (tl / tiles_w) * 8, tw = (tl % tiles_w) * 8;
+    const int wh0 = th - a.ph - T_R, ww0 = tw - a.pw - T_R;                 // input cell of window cell (0, 0)
+    const T* in = (const T*)a.in;
+    const T* off = (const T*)a.off;
+    const T* msk = (const T*)a.msk;
+    const T* imb = in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
+    float* gib = a.gin + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
+    for (int i = 0; i < 4; ++i) {
+        const int item = wave * 4 + i;
+        const int ho = th + (item >> 3), wo = tw + (item & 7);
+        float col[T_SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < T_SLOTS; ++sl) col[sl] = 0.f;
+        float go = 0.f;
+        if (ho < a.Ho && wo < a.Wo) {                                       // (uniform)
+            const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
+            go = ET<T>::ld((const T*)a.gout + (size_t)pix * C + g * a.Gc + lane);
+            const float p0w_ = (float)(1 - a.pw + wo) - 1.f, p0h_ = (float)(1 - a.ph + ho) - 1.f;      // dilation 1, offset_scale 1
+            const T* offp = off + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2;
+            const T* mskp = msk + (size_t)pix * a.G * P + (size_t)g * P;
+            int k = 0;
+            for (int ii = 0; ii < 3; ++ii)
+                for (int jj = 0; jj < 3; ++jj, ++k) {
+                    const float ow = ET<T>::ld(offp + 2 * k), oh = ET<T>::ld(offp + 2 * k + 1), mk = ET<T>::ld(mskp + k);
+                    const float lw_ = p0w_ + ((float)ii + ow);
+                    const float lh_ = p0h_ + ((float)jj + oh);
+                    float gmask = 0.f, goffw = 0.f, goffh = 0.f;
+                    if (dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {          // (uniform)
+                        const int hl = __builtin_amdgcn_readfirstlane((int)floorf(lh_)), wl = __builtin_amdgcn_readfirstlane((int)floorf(lw_));
+                        const int hh_ = hl + 1, wh_ = wl + 1;
+                        const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        const bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wh_ <= a.W - 1;
+                        const bool b3 = hh_ <= a.H - 1 && wl >= 0, b4 = hh_ <= a.H - 1 && wh_ <= a.W - 1;
+                        const size_t o1 = ((size_t)hl * a.W + wl) * C + lane, o2 = ((size_t)hl * a.W + wh_) * C + lane;
+                        const size_t o3 = ((size_t)hh_ * a.W + wl) * C + lane, o4 = ((size_t)hh_ * a.W + wh_) * C + lane;
+                        const float v1 = b1 ? ET<T>::ld(imb + o1) : 0.f;
+                        const float v2 = b2 ? ET<T>::ld(imb + o2) : 0.f;
+                        const float v3 = b3 ? ET<T>::ld(imb + o3) : 0.f;
+                        const float v4 = b4 ? ET<T>::ld(imb + o4) : 0.f;
+                        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                        const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                        const float tg = go * mk;
+                        const int r = hl - wh0, cc = wl - ww0;                // window cell of corner 1 (uniform)
+                        auto corner = [&](bool bb, float w, int rr, int cq, size_t o) {
+                            if (bb && w != 0.f) {                            // a corner with bilinear weight 0 adds nothing
+                                if ((unsigned)rr < (unsigned)T_WIN && (unsigned)cq < (unsigned)T_WIN) {
+                                    const int q = rr * T_WIN + cq;           // (uniform) lane q & 63 holds the cell in slot q >> 6
+                                    if (lane == (q & 63)) col[q >> 6] += w * mk;
+                                } else {
+                                    atomicAdd(gib + o, w * tg);              // beyond the window: straight to memory, as before
+                                }
+                            }
+                        };
+                        corner(b1, w1, r, cc, o1);
+                        corner(b2, w2, r, cc + 1, o2);
+                        corner(b3, w3, r + 1, cc, o3);
+                        corner(b4, w4, r + 1, cc + 1, o4);
+                        const float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
+                        const float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
+                        gmask = go * val;
+                        goffw = gww * tg;
+                        goffh = ghw * tg;
+                    }
+                    gmask = wave_total63(gmask);
+                    goffw = wave_total63(goffw);
+                    goffh = wave_total63(goffh);
+                    if (lane == 63) {
+                        float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + 2 * k;
+                        float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P + k;
+                        gof[0] = goffw; gof[1] = goffh; gmk[0] = gmask;
+                    }
+                }
+        }
+        // the pixel's column of S (zeros for a pixel beyond the image) and its grad_output row
+#pragma unroll
+        for (int sl = 0; sl < T_SLOTS; ++sl)
+            if (sl * 64 + lane < T_CPAD) sS[item * T_CPAD + sl * 64 + lane] = col[sl];
+        sGO[item * T_GOLD + lane] = go;
+    }
+    __syncthreads();
+    // ---- phase 2: D[cell][c] = sum_pixel S[pixel][cell] * GO[pixel][c]; cell tile mt (16 cells) x 4 channel tiles per wave
+    constexpr int NMT = T_CPAD / 16;                      // 21
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    f32x4_t d[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) d[u][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int mt = wave + 16 * u;
+        if (mt < NMT) {                                   // (uniform)
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const int pxl = k4 * 4 + lgrp;
+                const float av = sS[pxl * T_CPAD + mt * 16 + lrow];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    d[u][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sGO[pxl * T_GOLD + nt * 16 + lrow], d[u][nt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                      // every wave has read its part of S: the area becomes [cell][64 channels]
+    float* const sD = slds;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int mt = wave + 16 * u;
+        if (mt < NMT) {
+            // lane holds cells mt*16 + 4*lgrp + e, channel nt*16 + lrow; 64-byte blocks of a row XOR-ed by (cell >> 2) & 3
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cell = mt * 16 + 4 * lgrp + e;
+                    sD[cell * 64 + (((nt ^ ((cell >> 2) & 3)) << 4) | lrow)] = d[u][nt][e];
+                }
+            // (wave-private rows: a wave's own LDS operations complete in order)
+            for (int rr = 0; rr < 16; ++rr) {
+                const int cell = mt * 16 + rr;            // (uniform)
+                const int ch_h = wh0 + cell / T_WIN, ch_w = ww0 + cell % T_WIN;
+                if (cell < T_CELLS && (unsigned)ch_h < (unsigned)a.H && (unsigned)ch_w < (unsigned)a.W) {
+                    const float v = sD[cell * 64 + ((((lane >> 4) ^ ((cell >> 2) & 3)) << 4) | (lane & 15))];
+                    if (v != 0.f) atomicAdd(gib + ((size_t)ch_h * a.W + ch_w) * C + lane, v);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Forward, vectorised: a lane owns one 16-byte channel chunk (8 bf16/f16 or 4 f32 channels) of a (pixel, group) item, so
 // a 64-lane load instruction moves 1 KiB of gathered rows instead of 128-256 bytes; the offsets and masks of the CTA's
 // DCN_PIX consecutive pixels are staged once, coalesced, in LDS as f32 (every lane of an item reads the same 3*P values).
@@ -434,6 +598,20 @@ extern "C" int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, c
     hipStream_t st = (hipStream_t)stream;
     YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16 || dtype == YDL_F16, "bad dtype");
     static const int nowin = getenv("YDL_DCN_NOWIN") ? atoi(getenv("YDL_DCN_NOWIN")) : 0;
+    static const int notile = getenv("YDL_DCN_NOTILE") ? atoi(getenv("YDL_DCN_NOTILE")) : 0;
+    if (!nowin && !notile && g_dcn_win && g_dcn_tile && kernel_h == 3 && kernel_w == 3 && group_channels == 64 && stride_h == 1 && stride_w == 1 &&
+        dilation_h == 1 && dilation_w == 1 && offset_scale == 1.0f && H_out >= 8 && W_out >= 8) {
+        // 8 x 8 pixel tiles: the scatter into grad_input as S x grad_output on the f32 MFMA (dcnv3_bwd_tile_kernel)
+        const int tiles_w = (W_out + 7) / 8, tiles_hw = tiles_w * ((H_out + 7) / 8);
+        const long long blocks = (long long)N * group * tiles_hw;
+        YDL_CHECK(blocks < (1ll << 31), "too many tiles");
+        const size_t lds = (size_t)(64 * T_CPAD + 64 * T_GOLD) * sizeof(float);
+        if (dtype == YDL_F32) { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<float>), lds); dcnv3_bwd_tile_kernel<float><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
+        else if (dtype == YDL_BF16) { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<bf16_t>), lds); dcnv3_bwd_tile_kernel<bf16_t><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
+        else { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<_Float16>), lds); dcnv3_bwd_tile_kernel<_Float16><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
+        YDL_LAUNCH_CHECK();
+        return 0;
+    }
     if (!nowin && g_dcn_win && kernel_h == 3 && kernel_w == 3 && a.seg == 64) {
         // a whole wave per item: corner gradients merged in a register window before the atomics (dcnv3_bwd_win_kernel)
         long long blocks = (a.items + 3) / 4;

@@ -3534,13 +3534,22 @@ struct PwbwArgs {
     const bf16_t* X; const bf16_t* dY; const bf16_t* Wt; bf16_t* dX; float* dW;
     int M, ldx, ldy, lddx, ldw, chunk;
     unsigned bytesX, bytesY, bytesDX, bytesWt;
+    int dbg;
 };
 #define PWBW_SP 32
+// A 16-byte store issued from inline asm: the hardware reads the four data registers over two cycles AFTER issue, and a vector
+// instruction that rewrites one of them in the next cycle wins the race (the compiler's hazard recognizer pads a store it knows with
+// a wait state; it cannot see into an asm statement).  Found as an LDS address in every third dword of dx: the `s_nop` is the fix.
+__device__ __forceinline__ void buf_store16_asm(const u32x4& v, unsigned off, const u32x4& rsrc) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rsrc) : "memory");
+}
 template <int S, bool ACC>
 __global__ __launch_bounds__(512, 2) void pwbw_kernel(const PwbwArgs p) {
     constexpr int SP = PWBW_SP;
-    constexpr int YB = SP * 256, STAGE = 2 * YB;          // dy tile + x tile
-    constexpr int LOPS = ACC ? 4 : 3;                     // vector-memory operations per thread and stage: 2 DMAs, [old dx], store
+    constexpr int YB = SP * 256;                          // one 32-row tile
+    constexpr int NT = ACC ? 3 : 2;                       // tiles per stage: dy, x, [old dx]
+    constexpr int STAGE = NT * YB;
+    constexpr int LOPS = NT + 1;                          // vector-memory operations per thread and stage: NT DMAs + one store
     constexpr int NWAIT = (S - 2) * LOPS + 1;             // younger than a stage's DMAs when its turn comes: its own store + S - 2 stages
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const sWt = smem + S * STAGE;          // [128 ci][256 B of co], chunk q of row r at slot q ^ (r & 15)
@@ -3563,21 +3572,18 @@ __global__ __launch_bounds__(512, 2) void pwbw_kernel(const PwbwArgs p) {
     const int r = t >> 4, q = t & 15;
     const unsigned qlog = (unsigned)((((q >> 1) ^ w3f<256>(r)) << 1) | (q & 1)) << 4;
     const unsigned wave_lds = lds0 + (unsigned)wave * 1024u;
+    auto dx_off = [&](int p0) -> unsigned {
+        const int m = p0 + r;
+        return (m >= pbeg && m < pend) ? (unsigned)m * (unsigned)(p.lddx * 2) + (unsigned)(q << 4) : 0xFFFFFFFFu;
+    };
+    // a stage = 32 rows of dy and of x in the swizzled image, and (ACC) the previous contents of the same 32 rows of dx, unswizzled:
+    // thread (r, q) reads back exactly the 16 bytes its own DMA lane wrote
     auto issue = [&](int p0, int buf) {
         const int m = p0 + r;
         const bool ok = m < pend;
         lds_dma16(rsY, wave_lds + (unsigned)buf * STAGE, ok ? (unsigned)m * (unsigned)(p.ldy * 2) + qlog : 0xFFFFFFFFu);
         lds_dma16(rsX, wave_lds + (unsigned)buf * STAGE + YB, ok ? (unsigned)m * (unsigned)(p.ldx * 2) + qlog : 0xFFFFFFFFu);
-    };
-    // the old contents of this thread's 16 bytes of dx (row r, chunk q of the stage that began at p0); issued from asm so that the
-    // compiler's own wait-count insertion does not drain the ring for it (it counts only the operations it knows)
-    u32x4 old = u32x4{0u, 0u, 0u, 0u};
-    auto dx_off = [&](int p0) -> unsigned {
-        const int m = p0 + r;
-        return (m >= pbeg && m < pend) ? (unsigned)m * (unsigned)(p.lddx * 2) + (unsigned)(q << 4) : 0xFFFFFFFFu;
-    };
-    auto load_old = [&](int p0) {
-        if constexpr (ACC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(old) : "v"(dx_off(p0)), "s"(rsD) : "memory");
+        if constexpr (ACC) lds_dma16(rsD, wave_lds + (unsigned)buf * STAGE + 2 * YB, dx_off(p0));
     };
     // weights: 4 passes of 32 rows
 #pragma unroll
@@ -3586,12 +3592,11 @@ __global__ __launch_bounds__(512, 2) void pwbw_kernel(const PwbwArgs p) {
         lds_dma16(rsW, lds0 + (unsigned)(S * STAGE) + (unsigned)i * 8192u + (unsigned)wave * 1024u,
                   (unsigned)row * 256u + (unsigned)((q ^ (row & 15)) << 4));
     }
-    // prologue: S - 1 stages, each followed by the same dummy operations a loop iteration issues behind its DMAs
+    // prologue: S - 1 stages, each followed by the (dropped) store a loop iteration issues behind its DMAs: the count stays uniform
 #pragma unroll
     for (int u = 0; u < S - 1; ++u) {
-        if constexpr (ACC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(old) : "v"(0xFFFFFFFFu), "s"(rsD) : "memory");
         issue(pbeg + u * SP, u);
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(old), "v"(0xFFFFFFFFu), "s"(rsD) : "memory");
+        buf_store16_asm(u32x4{0u, 0u, 0u, 0u}, 0xFFFFFFFFu, rsD);
     }
 
     const int lrow = lane & 15, lgrp = lane >> 4;
@@ -3651,29 +3656,34 @@ __global__ __launch_bounds__(512, 2) void pwbw_kernel(const PwbwArgs p) {
             *(uint2*)(st + px * 256 + ((chq ^ (px & 15)) << 4) + ((lgrp & 1) << 3)) = u;
         }
     };
-    // the rows of the stage that began at p0 leave the staging tile: 16 bytes per thread, a whole pixel row per 16 lanes
-    auto store_rows = [&](int p0, int sbuf) {
-        const unsigned char* const st = sSt + sbuf * (SP * 256);
-        uint4 v = *(const uint4*)(st + r * 256 + ((q ^ (r & 15)) << 4));
+    // the rows of a finished stage: this thread's 16 bytes of the staging tile (and of the old dx tile that travelled with the stage)
+    auto fetch_rows = [&](int sbuf, int obuf, uint4& v, uint4& o) {
+        v = *(const uint4*)(sSt + sbuf * (SP * 256) + r * 256 + ((q ^ (r & 15)) << 4));
+        if constexpr (ACC) o = *(const uint4*)(smem + obuf * STAGE + 2 * YB + t * 16);
+    };
+    auto store_rows = [&](int p0, uint4 v, const uint4& o) {
         if constexpr (ACC) {
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(old) : "n"(2) : "memory");      // older than this stage's two DMAs only
             float a8[8], o8[8];
             unpack16<bf16_t>(v, a8);
-            unpack16<bf16_t>(make_uint4(old.x, old.y, old.z, old.w), o8);
+            unpack16<bf16_t>(o, o8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) a8[e] += o8[e];
             v = pack16<bf16_t>(a8);
         }
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u32x4{v.x, v.y, v.z, v.w}), "v"(dx_off(p0)), "s"(rsD) : "memory");
+        buf_store16_asm(u32x4{v.x, v.y, v.z, v.w}, dx_off(p0), rsD);
     };
 
     int buf = 0, nxt = S - 1, k = 0;
     for (int p0 = pbeg; p0 < pend; p0 += SP, ++k) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // own staging writes / fragment reads of the previous stage are done
+        if (p.dbg == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wait_vm_barrier<NWAIT>();
-        load_old(p0 - SP);                                       // (stage -1: out of range)
+        // the previous stage's rows come out of LDS BEFORE the DMAs below overwrite the buffer its old-dx tile sits in (nxt)
+        uint4 v, o = make_uint4(0u, 0u, 0u, 0u);
+        fetch_rows((k + 1) & 1, nxt, v, o);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w)::"memory");
         issue(p0 + (S - 1) * SP, nxt);
-        store_rows(p0 - SP, (k + 1) & 1);
+        store_rows(p0 - SP, v, o);                               // (stage -1: out-of-range offset, dropped)
         compute(buf, k & 1);
         buf = buf + 1 == S ? 0 : buf + 1;
         nxt = nxt + 1 == S ? 0 : nxt + 1;
@@ -3681,21 +3691,9 @@ __global__ __launch_bounds__(512, 2) void pwbw_kernel(const PwbwArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wait_vm_barrier<0>();
     if (k > 0) {
-        load_old(pbeg + (k - 1) * SP);
-        if constexpr (ACC) asm volatile("s_nop 0" ::: "memory");
-        // (no DMA follows: the wait inside store_rows must see the load as the only outstanding operation)
-        if constexpr (ACC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(old)::"memory");
-        const unsigned char* const st = sSt + ((k - 1) & 1) * (SP * 256);
-        uint4 v = *(const uint4*)(st + r * 256 + ((q ^ (r & 15)) << 4));
-        if constexpr (ACC) {
-            float a8[8], o8[8];
-            unpack16<bf16_t>(v, a8);
-            unpack16<bf16_t>(make_uint4(old.x, old.y, old.z, old.w), o8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a8[e] += o8[e];
-            v = pack16<bf16_t>(a8);
-        }
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u32x4{v.x, v.y, v.z, v.w}), "v"(dx_off(pbeg + (k - 1) * SP)), "s"(rsD) : "memory");
+        uint4 v, o = make_uint4(0u, 0u, 0u, 0u);
+        fetch_rows((k - 1) & 1, nxt, v, o);                      // (nxt == the last stage's buffer: (k - 1) % S)
+        store_rows(pbeg + (k - 1) * SP, v, o);
     }
     // weight gradient: one atomic pass over the CTA's 128 x 128 tile
 #pragma unroll
@@ -3745,15 +3743,18 @@ extern "C" int ydl_conv_bwd_pw(const ydl_conv_geom* g, int dtype, const void* x,
     a.bytesY = (unsigned)((unsigned long long)(M - 1) * g->ldy * 2ull + 256ull);
     a.bytesDX = (unsigned)((unsigned long long)(M - 1) * lddx * 2ull + 256ull);
     a.bytesWt = 128u * 256u;
+    a.dbg = getenv("YDL_PWBW_DBG") ? atoi(getenv("YDL_PWBW_DBG")) : 0;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int S = 5;
-    const size_t smem = (size_t)S * 2 * PWBW_SP * 256 + 128 * 256 + 2 * PWBW_SP * 256;
     ydl_note_kernel(1, accumulate ? "pwbw_kernel<128,128,acc>" : "pwbw_kernel<128,128>");
     ydl_note_kernel(2, "pwbw_kernel<128,128>");
-    if (accumulate) {
+    if (accumulate) {          // three tiles per stage (the old dx rows travel with the stage): four stages = 96 KB of ring
+        constexpr int S = 4;
+        const size_t smem = (size_t)S * 3 * PWBW_SP * 256 + 128 * 256 + 2 * PWBW_SP * 256;
         YDL_SET_MAX_LDS((pwbw_kernel<S, true>), smem);
         pwbw_kernel<S, true><<<ctas, 512, smem, st>>>(a);
     } else {
+        constexpr int S = 5;
+        const size_t smem = (size_t)S * 2 * PWBW_SP * 256 + 128 * 256 + 2 * PWBW_SP * 256;
         YDL_SET_MAX_LDS((pwbw_kernel<S, false>), smem);
         pwbw_kernel<S, false><<<ctas, 512, smem, st>>>(a);
     }
@@ -4054,6 +4055,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
+//              key 16 = DCNv3 tile backward (grad_input scatter as S x grad_output on the MFMA): 1 (default) on, 0 off
 //              key 15 = one-pass input + weight gradient of the 128 -> 128 1x1 layers (pwbw_kernel): 1 (default) on, 0 two launches
 //              key 14 = accumulating point-wise launches: 1 (default) per-wave transposed stores also with statistics, 2 only without, 0 never
 //              key 13 = DCNv3 backward with the register window (dcnv3_bwd_win_kernel): 1 (default) on, 0 plain per-corner atomics
