@@ -279,15 +279,17 @@ def test_dcnv3_border_rule_pins_both_conventions(Gc):
     assert torch.allclose(out["cuh"][0], ri.grad, **tol(ri.grad))
 
 
+@pytest.mark.parametrize("G,Gc", [(3, 64), (1, 128), (2, 192)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_dcnv3_tile_backward_against_the_oracle(dtype):
+def test_dcnv3_tile_backward_against_the_oracle(dtype, G, Gc):
     """dcnv3_bwd_tile_kernel (8 x 8 pixel tiles, grad_input = S x grad_output on the f32 MFMA, 18 x 18 cell windows) against the CPU
     oracle's autograd (functions/dcnv3_func.py:148-189) with offsets of sigma = 2.5 px: corners inside the window, beyond it (direct
-    atomics) and outside the image, image sizes that leave partial tiles, two images and three groups."""
+    atomics) and outside the image, image sizes that leave partial tiles, two images; three groups of 64 channels, and groups of 128 / 192
+    channels (chunks of 64 sharing one S; the config-5 model runs group 1 with 64 .. 256 channels)."""
     import ctypes
     from oracle import ref_cpu as R
     from yolo_dual_amd import _lib as L
-    N, H, W, G, Gc = 2, 21, 19, 3, 64
+    N, H, W = 2, 21, 19
     C = G * Gc
     g = torch.Generator().manual_seed(9)
     inp = torch.randn(N, H, W, C, generator=g)

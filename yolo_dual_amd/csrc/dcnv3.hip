@@ -41,6 +41,8 @@ struct DcnArgs {
     int seg;          // lanes per item (power of two, <= 64)
     long long items;  // N*Ho*Wo*G
     int strict;       // border rule: 0 ">= -1" (PyTorch core), 1 "> -1" (.cuh)
+    int dbg;          // timing experiments only (YDL_DCN_DBG): bit 0 no flush atomics, bit 1 no MFMA phase, bit 2 no direct atomics,
+                      //                                          bit 3 no gathers (corner values zero)
 };
 
 static int g_dcn_border_rule = 0;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Backward for 3 x 3 / stride 1 / dilation 1 / offset_scale 1 with 64 channels per group, round 5: the grad_input scatter as a MATRIX
+// Backward for 3 x 3 / stride 1 / dilation 1 / offset_scale 1, group widths that are multiples of 64, round 5: the grad_input scatter as a MATRIX
 // PRODUCT.  What every corner adds is (bilinear weight x mask) — one scalar per (output pixel, corner), the same for all channels —
 // times grad_output[pixel][c]:      grad_input[cell][c] = sum_pixels S[cell][pixel] * grad_output[pixel][c].
 // A CTA owns an 8 x 8 tile of output pixels of one (image, group) and the 18 x 18 window of input cells that sampling offsets
@@ -284,9 +286,11 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
 // four corners, grad_offset / grad_mask by DPP wave totals): the corner scalars do NOT go to memory — the wave keeps its pixel's
 // column of S in registers (cell q in lane q & 63, slot q >> 6; a uniform cell index, one lane adds) and writes it once, together
 // with its grad_output row (f32), to LDS: no atomics, no zero fill, every (pixel, cell) is written.  Phase 2: S x GO on the f32 MFMA
-// (v_mfma_f32_16x16x4_f32: exact f32 products, 21 x 4 tiles x 16 k-steps per CTA), transposed through the (now free) S area into
-// [cell][64 channels] rows, and each in-image, non-zero row leaves with ONE 256-byte atomic instruction: 83 KB of atomics per 64
-// pixels instead of 590 KB, whatever the offsets are.  Corners beyond the window (|offset| >= 4 px) keep their direct atomics.
+// (v_mfma_f32_16x16x4_f32: exact f32 products, 21 x 4 tiles x 16 k-steps per CTA and 64-channel chunk),
+// and the in-image, non-zero cells leave the accumulator registers as they stand (an atomic instruction = 4 cells x 16 channels: four
+// 64-byte pieces, the four memory-side requests a 256-byte row would make too): 83 KB of atomics per 64 pixels and 64 channels
+// instead of 590 KB, whatever the offsets are.  Groups wider than 64 channels run chunk by chunk with the SAME S (built once).
+// Corners beyond the window (|offset| >= 4 px) keep their direct atomics.
 // Reference arithmetic: dcnv3_im2col_cuda.cuh:82-147 (same products; the sum over pixels is formed in the MFMA's order).
 // ------------------------------------------------------------------------------------------------------
 #define T_R 4
@@ -300,7 +304,9 @@ template <typename T>
 __global__ __launch_bounds__(1024) void dcnv3_bwd_tile_kernel(const DcnArgs a, int tiles_w, int tiles_hw) {
     extern __shared__ __attribute__((aligned(16))) float slds[];
     float* const sS = slds;                              // [64 pixels][T_CPAD cells]  (S transposed: a pixel's column is contiguous)
-    float* const sGO = slds + 64 * T_CPAD;               // [64 pixels][T_GOLD]
+    float* const sGO = slds + 64 * T_CPAD;               // [64 pixels][T_GOLD]: grad_output of the current 64-channel chunk
+    float* const sOM = sGO + 64 * T_GOLD;                // [64 pixels][28]: the tile's 18 offsets + 9 masks per pixel as f32, staged once
+                                                         // (a wave per pixel reads them as LDS broadcasts instead of 27 global loads)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 16 waves, 4 pixels each
     constexpr int P = 9;
@@ -311,130 +317,133 @@ __global__ __launch_bounds__(1024) void dcnv3_bwd_tile_kernel(const DcnArgs a, i
     const int n = b / tiles_hw;
     const int th = (tl / tiles_w) * 8, tw = (tl % tiles_w) * 8;
     const int wh0 = th - a.ph - T_R, ww0 = tw - a.pw - T_R;                 // input cell of window cell (0, 0)
-    const T* in = (const T*)a.in;
     const T* off = (const T*)a.off;
     const T* msk = (const T*)a.msk;
-    const T* imb = in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
-    float* gib = a.gin + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc;
-    for (int i = 0; i < 4; ++i) {
-        const int item = wave * 4 + i;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    for (int e = threadIdx.x; e < 64 * 27; e += 1024) {
+        const int item = e / 27, j = e - item * 27;
         const int ho = th + (item >> 3), wo = tw + (item & 7);
-        float col[T_SLOTS];
-#pragma unroll
-        for (int sl = 0; sl < T_SLOTS; ++sl) col[sl] = 0.f;
-        float go = 0.f;
-        if (ho < a.Ho && wo < a.Wo) {                                       // (uniform)
+        float v = 0.f;
+        if (ho < a.Ho && wo < a.Wo) {
             const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
-            go = ET<T>::ld((const T*)a.gout + (size_t)pix * C + g * a.Gc + lane);
-            const float p0w_ = (float)(1 - a.pw + wo) - 1.f, p0h_ = (float)(1 - a.ph + ho) - 1.f;      // dilation 1, offset_scale 1
-            const T* offp = off + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2;
-            const T* mskp = msk + (size_t)pix * a.G * P + (size_t)g * P;
-            int k = 0;
-            for (int ii = 0; ii < 3; ++ii)
-                for (int jj = 0; jj < 3; ++jj, ++k) {
-                    const float ow = ET<T>::ld(offp + 2 * k), oh = ET<T>::ld(offp + 2 * k + 1), mk = ET<T>::ld(mskp + k);
-                    const float lw_ = p0w_ + ((float)ii + ow);
-                    const float lh_ = p0h_ + ((float)jj + oh);
-                    float gmask = 0.f, goffw = 0.f, goffh = 0.f;
-                    if (dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {          // (uniform)
-                        const int hl = __builtin_amdgcn_readfirstlane((int)floorf(lh_)), wl = __builtin_amdgcn_readfirstlane((int)floorf(lw_));
-                        const int hh_ = hl + 1, wh_ = wl + 1;
-                        const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
-                        const float hh = 1.f - lh, hw = 1.f - lw;
-                        const bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wh_ <= a.W - 1;
-                        const bool b3 = hh_ <= a.H - 1 && wl >= 0, b4 = hh_ <= a.H - 1 && wh_ <= a.W - 1;
-                        const size_t o1 = ((size_t)hl * a.W + wl) * C + lane, o2 = ((size_t)hl * a.W + wh_) * C + lane;
-                        const size_t o3 = ((size_t)hh_ * a.W + wl) * C + lane, o4 = ((size_t)hh_ * a.W + wh_) * C + lane;
-                        const float v1 = b1 ? ET<T>::ld(imb + o1) : 0.f;
-                        const float v2 = b2 ? ET<T>::ld(imb + o2) : 0.f;
-                        const float v3 = b3 ? ET<T>::ld(imb + o3) : 0.f;
-                        const float v4 = b4 ? ET<T>::ld(imb + o4) : 0.f;
-                        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                        const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                        const float tg = go * mk;
-                        const int r = hl - wh0, cc = wl - ww0;                // window cell of corner 1 (uniform)
-                        auto corner = [&](bool bb, float w, int rr, int cq, size_t o) {
-                            if (bb && w != 0.f) {                            // a corner with bilinear weight 0 adds nothing
-                                if ((unsigned)rr < (unsigned)T_WIN && (unsigned)cq < (unsigned)T_WIN) {
-                                    const int q = rr * T_WIN + cq;           // (uniform) lane q & 63 holds the cell in slot q >> 6
-                                    if (lane == (q & 63)) col[q >> 6] += w * mk;
-                                } else {
-                                    atomicAdd(gib + o, w * tg);              // beyond the window: straight to memory, as before
-                                }
-                            }
-                        };
-                        corner(b1, w1, r, cc, o1);
-                        corner(b2, w2, r, cc + 1, o2);
-                        corner(b3, w3, r + 1, cc, o3);
-                        corner(b4, w4, r + 1, cc + 1, o4);
-                        const float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
-                        const float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
-                        gmask = go * val;
-                        goffw = gww * tg;
-                        goffh = ghw * tg;
-                    }
-                    gmask = wave_total63(gmask);
-                    goffw = wave_total63(goffw);
-                    goffh = wave_total63(goffh);
-                    if (lane == 63) {
-                        float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + 2 * k;
-                        float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P + k;
-                        gof[0] = goffw; gof[1] = goffh; gmk[0] = gmask;
-                    }
-                }
+            v = j < 18 ? ET<T>::ld(off + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + j)
+                       : ET<T>::ld(msk + (size_t)pix * a.G * P + (size_t)g * P + (j - 18));
         }
-        // the pixel's column of S (zeros for a pixel beyond the image) and its grad_output row
-#pragma unroll
-        for (int sl = 0; sl < T_SLOTS; ++sl)
-            if (sl * 64 + lane < T_CPAD) sS[item * T_CPAD + sl * 64 + lane] = col[sl];
-        sGO[item * T_GOLD + lane] = go;
+        sOM[item * 28 + j] = v;
     }
     __syncthreads();
-    // ---- phase 2: D[cell][c] = sum_pixel S[pixel][cell] * GO[pixel][c]; cell tile mt (16 cells) x 4 channel tiles per wave
-    constexpr int NMT = T_CPAD / 16;                      // 21
-    const int lrow = lane & 15, lgrp = lane >> 4;
-    f32x4_t d[2][4];
+    // channel chunks of 64 (Gc is a multiple of 64): S is built with the first chunk and serves all of them
+    for (int c0 = 0; c0 < a.Gc; c0 += 64) {
+        const T* imb = (const T*)a.in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc + c0;
+        float* gib = a.gin + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc + c0;
+        for (int i = 0; i < 4; ++i) {
+            const int item = wave * 4 + i;
+            const int ho = th + (item >> 3), wo = tw + (item & 7);
+            float col[T_SLOTS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+            for (int sl = 0; sl < T_SLOTS; ++sl) col[sl] = 0.f;
+            float go = 0.f;
+            if (ho < a.Ho && wo < a.Wo) {                                       // (uniform)
+                const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
+                go = ET<T>::ld((const T*)a.gout + (size_t)pix * C + g * a.Gc + c0 + lane);
+                const float p0w_ = (float)(1 - a.pw + wo) - 1.f, p0h_ = (float)(1 - a.ph + ho) - 1.f;      // dilation 1, offset_scale 1
+                const float* const om = sOM + item * 28;
+                int k = 0;
+                for (int ii = 0; ii < 3; ++ii)
+                    for (int jj = 0; jj < 3; ++jj, ++k) {
+                        const float ow = om[2 * k], oh = om[2 * k + 1], mk = om[18 + k];
+                        const float lw_ = p0w_ + ((float)ii + ow);
+                        const float lh_ = p0h_ + ((float)jj + oh);
+                        float gmask = 0.f, goffw = 0.f, goffh = 0.f;
+                        if (dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {          // (uniform)
+                            const int hl = __builtin_amdgcn_readfirstlane((int)floorf(lh_)), wl = __builtin_amdgcn_readfirstlane((int)floorf(lw_));
+                            const int hh_ = hl + 1, wh_ = wl + 1;
+                            const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
+                            const float hh = 1.f - lh, hw = 1.f - lw;
+                            const bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wh_ <= a.W - 1;
+                            const bool b3 = hh_ <= a.H - 1 && wl >= 0, b4 = hh_ <= a.H - 1 && wh_ <= a.W - 1;
+                            const size_t o1 = ((size_t)hl * a.W + wl) * C + lane, o2 = ((size_t)hl * a.W + wh_) * C + lane;
+                            const size_t o3 = ((size_t)hh_ * a.W + wl) * C + lane, o4 = ((size_t)hh_ * a.W + wh_) * C + lane;
+                            const bool ld_ = !(a.dbg & 8);
+                            const float v1 = (b1 && ld_) ? ET<T>::ld(imb + o1) : 0.f;
+                            const float v2 = (b2 && ld_) ? ET<T>::ld(imb + o2) : 0.f;
+                            const float v3 = (b3 && ld_) ? ET<T>::ld(imb + o3) : 0.f;
+                            const float v4 = (b4 && ld_) ? ET<T>::ld(imb + o4) : 0.f;
+                            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                            const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                            const float tg = go * mk;
+                            const int r = hl - wh0, cc = wl - ww0;                // window cell of corner 1 (uniform)
+                            auto corner = [&](bool bb, float w, int rr, int cq, size_t o) {
+                                if (bb && w != 0.f) {                            // a corner with bilinear weight 0 adds nothing
+                                    if ((unsigned)rr < (unsigned)T_WIN && (unsigned)cq < (unsigned)T_WIN) {
+                                        const int q = rr * T_WIN + cq;           // (uniform) lane q & 63 holds the cell in slot q >> 6
+                                        if (c0 == 0 && lane == (q & 63)) col[q >> 6] += w * mk;
+                                    } else if (!(a.dbg & 4)) {
+                                        atomicAdd(gib + o, w * tg);              // beyond the window: straight to memory, as before
+                                    }
+                                }
+                            };
+                            corner(b1, w1, r, cc, o1);
+                            corner(b2, w2, r, cc + 1, o2);
+                            corner(b3, w3, r + 1, cc, o3);
+                            corner(b4, w4, r + 1, cc + 1, o4);
+                            const float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
+                            const float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
+                            gmask = go * val;
+                            goffw = gww * tg;
+                            goffh = ghw * tg;
+                        }
+                        gmask = wave_total63(gmask);
+                        goffw = wave_total63(goffw);
+                        goffh = wave_total63(goffh);
+                        if (lane == 63) {
+                            float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + 2 * k;
+                            float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P + k;
+                            if (c0 == 0) { gof[0] = goffw; gof[1] = goffh; gmk[0] = gmask; }
+                            else { gof[0] += goffw; gof[1] += goffh; gmk[0] += gmask; }     // (same lane, program order: as the kernels above)
+                        }
+                    }
+            }
+            // the pixel's column of S (zeros for a pixel beyond the image) and its grad_output row
+            if (c0 == 0) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) d[u][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int sl = 0; sl < T_SLOTS; ++sl)
+                    if (sl * 64 + lane < T_CPAD) sS[item * T_CPAD + sl * 64 + lane] = col[sl];
+            }
+            sGO[item * T_GOLD + lane] = go;
+        }
+        __syncthreads();
+        // ---- phase 2: D[cell][c] = sum_pixel S[pixel][cell] * GO[pixel][c]; cell tile mt (16 cells) x 4 channel tiles per wave.
+        // A lane ends with cells mt*16 + 4*lgrp + e, channel nt*16 + lrow: an atomic instruction covers 4 cells x 16 channels —
+        // four 64-byte pieces, the same four memory-side requests a contiguous 256-byte row makes
+        constexpr int NMT = T_CPAD / 16;                      // 21
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            const int mt = wave + 16 * u;
+            if (mt >= NMT || (a.dbg & 2)) break;              // (uniform)
+            f32x4_t d[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int mt = wave + 16 * u;
-        if (mt < NMT) {                                   // (uniform)
+            for (int nt = 0; nt < 4; ++nt) d[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             for (int k4 = 0; k4 < 16; ++k4) {
                 const int pxl = k4 * 4 + lgrp;
                 const float av = sS[pxl * T_CPAD + mt * 16 + lrow];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    d[u][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sGO[pxl * T_GOLD + nt * 16 + lrow], d[u][nt], 0, 0, 0);
+                    d[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sGO[pxl * T_GOLD + nt * 16 + lrow], d[nt], 0, 0, 0);
             }
-        }
-    }
-    __syncthreads();                                      // every wave has read its part of S: the area becomes [cell][64 channels]
-    float* const sD = slds;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int mt = wave + 16 * u;
-        if (mt < NMT) {
-            // lane holds cells mt*16 + 4*lgrp + e, channel nt*16 + lrow; 64-byte blocks of a row XOR-ed by (cell >> 2) & 3
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cell = mt * 16 + 4 * lgrp + e;
-                    sD[cell * 64 + (((nt ^ ((cell >> 2) & 3)) << 4) | lrow)] = d[u][nt][e];
-                }
-            // (wave-private rows: a wave's own LDS operations complete in order)
-            for (int rr = 0; rr < 16; ++rr) {
-                const int cell = mt * 16 + rr;            // (uniform)
+            for (int e = 0; e < 4; ++e) {
+                const int cell = mt * 16 + 4 * lgrp + e;
                 const int ch_h = wh0 + cell / T_WIN, ch_w = ww0 + cell % T_WIN;
                 if (cell < T_CELLS && (unsigned)ch_h < (unsigned)a.H && (unsigned)ch_w < (unsigned)a.W) {
-                    const float v = sD[cell * 64 + ((((lane >> 4) ^ ((cell >> 2) & 3)) << 4) | (lane & 15))];
-                    if (v != 0.f) atomicAdd(gib + ((size_t)ch_h * a.W + ch_w) * C + lane, v);
+                    float* dst = gib + ((size_t)ch_h * a.W + ch_w) * C + lrow;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        if (d[nt][e] != 0.f && !(a.dbg & 1)) atomicAdd(dst + nt * 16, d[nt][e]);
                 }
             }
         }
+        __syncthreads();                                      // GO (and nothing else) is rewritten by the next chunk
     }
 }
 
@@ -537,6 +546,8 @@ static int fill_args(DcnArgs& a, int kernel_h, int kernel_w, int stride_h, int s
     a.seg = seg;
     a.items = (long long)N * H_out * W_out * group;
     a.strict = g_dcn_border_rule;
+    static const int dbg = getenv("YDL_DCN_DBG") ? atoi(getenv("YDL_DCN_DBG")) : 0;
+    a.dbg = dbg;
     return 0;
 }
 
@@ -599,13 +610,16 @@ extern "C" int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, c
     YDL_CHECK(dtype == YDL_F32 || dtype == YDL_BF16 || dtype == YDL_F16, "bad dtype");
     static const int nowin = getenv("YDL_DCN_NOWIN") ? atoi(getenv("YDL_DCN_NOWIN")) : 0;
     static const int notile = getenv("YDL_DCN_NOTILE") ? atoi(getenv("YDL_DCN_NOTILE")) : 0;
-    if (!nowin && !notile && g_dcn_win && g_dcn_tile && kernel_h == 3 && kernel_w == 3 && group_channels == 64 && stride_h == 1 && stride_w == 1 &&
-        dilation_h == 1 && dilation_w == 1 && offset_scale == 1.0f && H_out >= 8 && W_out >= 8) {
+    if (!nowin && !notile && g_dcn_win && g_dcn_tile && kernel_h == 3 && kernel_w == 3 && group_channels % 64 == 0 && stride_h == 1 && stride_w == 1 &&
+        dilation_h == 1 && dilation_w == 1 && offset_scale == 1.0f && H_out >= 8 && W_out >= 8 &&
+        (long long)N * group * ((W_out + 7) / 8) * ((H_out + 7) / 8) >= 2ll * ydl_device_cus()) {
+        // (a CTA per tile and group, one per CU: maps with fewer than two rounds of tiles — 20 x 20 at batch 16 — keep the
+        //  wave-per-pixel kernels: 145 / 203 us against 244 / 295 us at sigma 0 / 2)
         // 8 x 8 pixel tiles: the scatter into grad_input as S x grad_output on the f32 MFMA (dcnv3_bwd_tile_kernel)
         const int tiles_w = (W_out + 7) / 8, tiles_hw = tiles_w * ((H_out + 7) / 8);
         const long long blocks = (long long)N * group * tiles_hw;
         YDL_CHECK(blocks < (1ll << 31), "too many tiles");
-        const size_t lds = (size_t)(64 * T_CPAD + 64 * T_GOLD) * sizeof(float);
+        const size_t lds = (size_t)(64 * T_CPAD + 64 * T_GOLD + 64 * 28) * sizeof(float);
         if (dtype == YDL_F32) { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<float>), lds); dcnv3_bwd_tile_kernel<float><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
         else if (dtype == YDL_BF16) { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<bf16_t>), lds); dcnv3_bwd_tile_kernel<bf16_t><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
         else { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<_Float16>), lds); dcnv3_bwd_tile_kernel<_Float16><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }

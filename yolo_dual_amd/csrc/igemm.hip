@@ -2534,7 +2534,9 @@ static int launch_igemm2s(IgemmArgs a, hipStream_t st, int fam) {
     a.grid_n = (a.Cst + 63) / 64;
     a.grid_m = a.N * (a.Hi >> 3) * (a.Wi >> 4);
     YDL_CHECK(a.bytesB < 0x08000000u, "ring kernel: weight matrix of 128 MiB or more is not supported");
-    static const int stages = getenv("YDL_S2_STAGES") ? atoi(getenv("YDL_S2_STAGES")) : 3;       // tuning
+    // two weight stages everywhere (round 5): the three-stage form spills 9 VGPRs at the 128-register budget of four waves per SIMD and
+    // measured 2..5 % slower on both layers that run it (64->128 @160^2: 118.8 vs 112.8 us, 128->256 @80^2: 96.9 vs 94.9 us)
+    static const int stages = getenv("YDL_S2_STAGES") ? atoi(getenv("YDL_S2_STAGES")) : 2;       // tuning
     // (accumulate: the two-stage form — the three-stage one spills inside its block loop: 64->128 @160^2 143 against 153 us)
     if (a.accumulate) return stages == 33 ? launch_igemm2s_cfg<3, true>(a, st, fam) : launch_igemm2s_cfg<2, true>(a, st, fam);
     return stages == 2 ? launch_igemm2s_cfg<2, false>(a, st, fam) : launch_igemm2s_cfg<3, false>(a, st, fam);
