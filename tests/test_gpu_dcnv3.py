@@ -256,6 +256,7 @@ def test_dcnv3_border_rule_pins_both_conventions(Gc):
     o6 = off.view(N, H, W, G, P, 2)
     edge = ((wo - 1 + pi + o6[..., 0]) == -1) | ((ho - 1 + pj + o6[..., 1]) == -1)
     assert int(edge.sum()) > 0
+    L.debug_set(16, 2)          # the tile backward at any map size (Gc = 64: its partial tiles; Gc = 16 does not qualify)
     try:
         out = {}
         for rule in ("core", "cuh"):
@@ -266,6 +267,7 @@ def test_dcnv3_border_rule_pins_both_conventions(Gc):
             out[rule] = (gin.cpu(), goff.cpu().view(N, H, W, G, P, 2), gmsk.cpu().view(N, H, W, G, P))
     finally:
         ydl.config.set_dcnv3_border_rule("core")
+        L.debug_set(16, 1)
     tol = lambda r: dict(rtol=1e-3, atol=max(1e-5, 2e-5 * float(r.abs().max())))
     # core rule = the oracle, everywhere
     assert torch.allclose(out["core"][0], ri.grad, **tol(ri.grad))
@@ -303,7 +305,11 @@ def test_dcnv3_tile_backward_against_the_oracle(dtype, G, Gc):
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     dt = L.YDL_BF16 if dtype == "bf16" else L.YDL_F32
     gin = torch.zeros(N, H, W, C, device="cuda")
-    goff, gmsk = _dcn_bwd_raw(dt, inp.cuda().to(tdt), off.cuda().to(tdt), msk.cuda().to(tdt), go.cuda().to(tdt), gin, G, Gc)
+    L.debug_set(16, 2)          # (54 tiles: below the two-rounds rule of the dispatch)
+    try:
+        goff, gmsk = _dcn_bwd_raw(dt, inp.cuda().to(tdt), off.cuda().to(tdt), msk.cuda().to(tdt), go.cuda().to(tdt), gin, G, Gc)
+    finally:
+        L.debug_set(16, 1)
     tol = lambda r: dict(rtol=2e-3, atol=max(1e-5, 5e-5 * float(r.abs().max())))
     assert torch.allclose(gin.cpu(), ri.grad, **tol(ri.grad)), float((gin.cpu() - ri.grad).abs().max())
     assert torch.allclose(goff.cpu(), ro.grad, **tol(ro.grad)), float((goff.cpu() - ro.grad).abs().max())

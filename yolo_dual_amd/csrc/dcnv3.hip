@@ -47,7 +47,8 @@ struct DcnArgs {
 
 static int g_dcn_border_rule = 0;
 static int g_dcn_win = 1;          // ydl_debug_set key 13 (YDL_DCN_NOWIN=1 at start-up switches the window backward off)
-static int g_dcn_tile = 1;         // ydl_debug_set key 16: 1 (default) tile backward (S x grad_output on the MFMA) where it applies, 0 off
+static int g_dcn_tile = 1;         // ydl_debug_set key 16: 1 (default) tile backward (S x grad_output on the MFMA) where it applies and the
+                                   // map has two rounds of tiles, 2 = at any size (tests), 0 off
 extern "C" void ydl_dcnv3_set_border_rule(int rule) { g_dcn_border_rule = rule ? 1 : 0; }
 extern "C" int ydl_dcnv3_get_border_rule(void) { return g_dcn_border_rule; }
 void ydl_dcn_debug_set(int key, int val) { if (key == 13) g_dcn_win = val; if (key == 16) g_dcn_tile = val; }
@@ -300,13 +301,14 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const DcnArgs a) {
 #define T_SLOTS ((T_CPAD + 63) / 64)         // 6 column registers per lane
 #define T_GOLD 80                            // GO row stride (floats): 16 banks per row => conflict-free 16x16x4 B-operand reads
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define T_REC 8                               // dwords per (pixel, point) record
 template <typename T>
 __global__ __launch_bounds__(1024) void dcnv3_bwd_tile_kernel(const DcnArgs a, int tiles_w, int tiles_hw) {
     extern __shared__ __attribute__((aligned(16))) float slds[];
     float* const sS = slds;                              // [64 pixels][T_CPAD cells]  (S transposed: a pixel's column is contiguous)
     float* const sGO = slds + 64 * T_CPAD;               // [64 pixels][T_GOLD]: grad_output of the current 64-channel chunk
-    float* const sOM = sGO + 64 * T_GOLD;                // [64 pixels][28]: the tile's 18 offsets + 9 masks per pixel as f32, staged once
-                                                         // (a wave per pixel reads them as LDS broadcasts instead of 27 global loads)
+    int* const sRec = (int*)(sGO + 64 * T_GOLD);         // [64 pixels][9 points][T_REC]: everything about a sampling point that does not
+                                                         // depend on the channel, computed ONCE by one lane (pre-pass below)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 16 waves, 4 pixels each
     constexpr int P = 9;
@@ -320,22 +322,52 @@ __global__ __launch_bounds__(1024) void dcnv3_bwd_tile_kernel(const DcnArgs a, i
     const T* off = (const T*)a.off;
     const T* msk = (const T*)a.msk;
     const int lrow = lane & 15, lgrp = lane >> 4;
-    for (int e = threadIdx.x; e < 64 * 27; e += 1024) {
-        const int item = e / 27, j = e - item * 27;
+    // ---- pre-pass: a lane per (pixel, point).  A wave per pixel did this arithmetic 64 times over (position, floor, four bounds tests,
+    // four 64-bit offsets per point: the kernel was bound by exactly that — with every atomic, gather and MFMA switched off it kept
+    // 75 % of its time).  Record: [0] element offset of corner 1 in the image plane ((hl W + wl) C, may be negative), [1] flags: bit 0
+    // inside, bits 1-4 corner usable (in the image, non-zero weight), bits 5-8 corner inside the window, [2] window cell of corner 1,
+    // [3] lh, [4] lw, [5] mask
+    for (int e = threadIdx.x; e < 64 * P; e += 1024) {
+        const int item = e / P, k = e - item * P;
+        const int ii = k / 3, jj = k - ii * 3;
         const int ho = th + (item >> 3), wo = tw + (item & 7);
-        float v = 0.f;
+        int base = 0, flags = 0, q1 = 0;
+        float lh = 0.f, lw = 0.f, mk = 0.f;
         if (ho < a.Ho && wo < a.Wo) {
             const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
-            v = j < 18 ? ET<T>::ld(off + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + j)
-                       : ET<T>::ld(msk + (size_t)pix * a.G * P + (size_t)g * P + (j - 18));
+            const T* offp = off + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2;
+            const float ow = ET<T>::ld(offp + 2 * k), oh = ET<T>::ld(offp + 2 * k + 1);
+            mk = ET<T>::ld(msk + (size_t)pix * a.G * P + (size_t)g * P + k);
+            const float lw_ = ((float)(1 - a.pw + wo) - 1.f) + ((float)ii + ow);                  // dilation 1, offset_scale 1
+            const float lh_ = ((float)(1 - a.ph + ho) - 1.f) + ((float)jj + oh);
+            if (dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {
+                const int hl = (int)floorf(lh_), wl = (int)floorf(lw_);
+                lh = lh_ - (float)hl; lw = lw_ - (float)wl;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wl + 1 <= a.W - 1;
+                const bool b3 = hl + 1 <= a.H - 1 && wl >= 0, b4 = hl + 1 <= a.H - 1 && wl + 1 <= a.W - 1;
+                const int r = hl - wh0, cc = wl - ww0;
+                const bool i1 = (unsigned)r < (unsigned)T_WIN && (unsigned)cc < (unsigned)T_WIN;
+                const bool i2 = (unsigned)r < (unsigned)T_WIN && (unsigned)(cc + 1) < (unsigned)T_WIN;
+                const bool i3 = (unsigned)(r + 1) < (unsigned)T_WIN && (unsigned)cc < (unsigned)T_WIN;
+                const bool i4 = (unsigned)(r + 1) < (unsigned)T_WIN && (unsigned)(cc + 1) < (unsigned)T_WIN;
+                flags = 1 | ((b1 && hh * hw != 0.f) ? 2 : 0) | ((b2 && hh * lw != 0.f) ? 4 : 0) | ((b3 && lh * hw != 0.f) ? 8 : 0) |
+                        ((b4 && lh * lw != 0.f) ? 16 : 0) | (i1 ? 32 : 0) | (i2 ? 64 : 0) | (i3 ? 128 : 0) | (i4 ? 256 : 0) |
+                        (b1 ? 512 : 0) | (b2 ? 1024 : 0) | (b3 ? 2048 : 0) | (b4 ? 4096 : 0);          // bits 9-12: corner in the image
+                base = (hl * a.W + wl) * C;                               // (|.| < 2^31: the plane has fewer than 2^31 elements)
+                q1 = r * T_WIN + cc;
+            }
         }
-        sOM[item * 28 + j] = v;
+        int* rec = sRec + e * T_REC;
+        rec[0] = base; rec[1] = flags; rec[2] = q1;
+        rec[3] = __float_as_int(lh); rec[4] = __float_as_int(lw); rec[5] = __float_as_int(mk);
     }
     __syncthreads();
     // channel chunks of 64 (Gc is a multiple of 64): S is built with the first chunk and serves all of them
     for (int c0 = 0; c0 < a.Gc; c0 += 64) {
-        const T* imb = (const T*)a.in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc + c0;
+        const T* imb = (const T*)a.in + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc + c0 + lane;
         float* gib = a.gin + (size_t)n * a.H * a.W * C + (size_t)g * a.Gc + c0;
+        const int rowC = a.W * C;
         for (int i = 0; i < 4; ++i) {
             const int item = wave * 4 + i;
             const int ho = th + (item >> 3), wo = tw + (item & 7);
@@ -343,66 +375,63 @@ __global__ __launch_bounds__(1024) void dcnv3_bwd_tile_kernel(const DcnArgs a, i
 #pragma unroll
             for (int sl = 0; sl < T_SLOTS; ++sl) col[sl] = 0.f;
             float go = 0.f;
-            if (ho < a.Ho && wo < a.Wo) {                                       // (uniform)
-                const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
+            float r_off = 0.f, r_msk = 0.f;            // lane 2k / 2k+1: grad_offset (w, h) of point k; lane k: grad_mask of point k
+            const bool live = ho < a.Ho && wo < a.Wo;                          // (uniform)
+            long long pix = 0;
+            if (live) {
+                pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
                 go = ET<T>::ld((const T*)a.gout + (size_t)pix * C + g * a.Gc + c0 + lane);
-                const float p0w_ = (float)(1 - a.pw + wo) - 1.f, p0h_ = (float)(1 - a.ph + ho) - 1.f;      // dilation 1, offset_scale 1
-                const float* const om = sOM + item * 28;
-                int k = 0;
-                for (int ii = 0; ii < 3; ++ii)
-                    for (int jj = 0; jj < 3; ++jj, ++k) {
-                        const float ow = om[2 * k], oh = om[2 * k + 1], mk = om[18 + k];
-                        const float lw_ = p0w_ + ((float)ii + ow);
-                        const float lh_ = p0h_ + ((float)jj + oh);
-                        float gmask = 0.f, goffw = 0.f, goffh = 0.f;
-                        if (dcn_inside(lh_, lw_, a.H, a.W, a.strict)) {          // (uniform)
-                            const int hl = __builtin_amdgcn_readfirstlane((int)floorf(lh_)), wl = __builtin_amdgcn_readfirstlane((int)floorf(lw_));
-                            const int hh_ = hl + 1, wh_ = wl + 1;
-                            const float lh = lh_ - (float)hl, lw = lw_ - (float)wl;
-                            const float hh = 1.f - lh, hw = 1.f - lw;
-                            const bool b1 = hl >= 0 && wl >= 0, b2 = hl >= 0 && wh_ <= a.W - 1;
-                            const bool b3 = hh_ <= a.H - 1 && wl >= 0, b4 = hh_ <= a.H - 1 && wh_ <= a.W - 1;
-                            const size_t o1 = ((size_t)hl * a.W + wl) * C + lane, o2 = ((size_t)hl * a.W + wh_) * C + lane;
-                            const size_t o3 = ((size_t)hh_ * a.W + wl) * C + lane, o4 = ((size_t)hh_ * a.W + wh_) * C + lane;
-                            const bool ld_ = !(a.dbg & 8);
-                            const float v1 = (b1 && ld_) ? ET<T>::ld(imb + o1) : 0.f;
-                            const float v2 = (b2 && ld_) ? ET<T>::ld(imb + o2) : 0.f;
-                            const float v3 = (b3 && ld_) ? ET<T>::ld(imb + o3) : 0.f;
-                            const float v4 = (b4 && ld_) ? ET<T>::ld(imb + o4) : 0.f;
-                            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                            const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                            const float tg = go * mk;
-                            const int r = hl - wh0, cc = wl - ww0;                // window cell of corner 1 (uniform)
-                            auto corner = [&](bool bb, float w, int rr, int cq, size_t o) {
-                                if (bb && w != 0.f) {                            // a corner with bilinear weight 0 adds nothing
-                                    if ((unsigned)rr < (unsigned)T_WIN && (unsigned)cq < (unsigned)T_WIN) {
-                                        const int q = rr * T_WIN + cq;           // (uniform) lane q & 63 holds the cell in slot q >> 6
-                                        if (c0 == 0 && lane == (q & 63)) col[q >> 6] += w * mk;
-                                    } else if (!(a.dbg & 4)) {
-                                        atomicAdd(gib + o, w * tg);              // beyond the window: straight to memory, as before
-                                    }
+                const int* recp = sRec + item * P * T_REC;
+#pragma unroll 1
+                for (int k = 0; k < P; ++k, recp += T_REC) {
+                    const int flags = __builtin_amdgcn_readfirstlane(recp[1]);
+                    float gmask = 0.f, goffw = 0.f, goffh = 0.f;
+                    if (flags & 1) {                                           // (uniform)
+                        const int base = __builtin_amdgcn_readfirstlane(recp[0]);
+                        const int q1 = __builtin_amdgcn_readfirstlane(recp[2]);
+                        const float lh = __int_as_float(recp[3]), lw = __int_as_float(recp[4]), mk = __int_as_float(recp[5]);
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        const bool ld_ = !(a.dbg & 8);
+                        const float v1 = ((flags & 512) && ld_) ? ET<T>::ld(imb + base) : 0.f;
+                        const float v2 = ((flags & 1024) && ld_) ? ET<T>::ld(imb + base + C) : 0.f;
+                        const float v3 = ((flags & 2048) && ld_) ? ET<T>::ld(imb + base + rowC) : 0.f;
+                        const float v4 = ((flags & 4096) && ld_) ? ET<T>::ld(imb + base + rowC + C) : 0.f;
+                        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                        const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                        const float tg = go * mk;
+                        auto corner = [&](int ubit, int ibit, float w, int q, int o) {
+                            if (flags & ubit) {                                // usable: in the image, weight not zero
+                                if (flags & ibit) {                            // inside the window: the column of S (first chunk only)
+                                    if (c0 == 0 && lane == (q & 63)) col[q >> 6] += w * mk;
+                                } else if (!(a.dbg & 4)) {
+                                    atomicAdd(gib + o + lane, w * tg);         // beyond the window: straight to memory, as before
                                 }
-                            };
-                            corner(b1, w1, r, cc, o1);
-                            corner(b2, w2, r, cc + 1, o2);
-                            corner(b3, w3, r + 1, cc, o3);
-                            corner(b4, w4, r + 1, cc + 1, o4);
-                            const float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
-                            const float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
-                            gmask = go * val;
-                            goffw = gww * tg;
-                            goffh = ghw * tg;
-                        }
-                        gmask = wave_total63(gmask);
-                        goffw = wave_total63(goffw);
-                        goffh = wave_total63(goffh);
-                        if (lane == 63) {
-                            float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2 + 2 * k;
-                            float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P + k;
-                            if (c0 == 0) { gof[0] = goffw; gof[1] = goffh; gmk[0] = gmask; }
-                            else { gof[0] += goffw; gof[1] += goffh; gmk[0] += gmask; }     // (same lane, program order: as the kernels above)
-                        }
+                            }
+                        };
+                        corner(2, 32, w1, q1, base);
+                        corner(4, 64, w2, q1 + 1, base + C);
+                        corner(8, 128, w3, q1 + T_WIN, base + rowC);
+                        corner(16, 256, w4, q1 + T_WIN + 1, base + rowC + C);
+                        const float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;   // d val / d h
+                        const float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;   // d val / d w
+                        gmask = go * val;
+                        goffw = gww * tg;
+                        goffh = ghw * tg;
                     }
+                    gmask = wave_total63(gmask);
+                    goffw = wave_total63(goffw);
+                    goffh = wave_total63(goffh);
+                    // park the three totals (lane 63) in the lanes that will store them: 18 + 9 contiguous floats per pixel and group
+                    const float tm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gmask), 63));
+                    const float tw_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(goffw), 63));
+                    const float th_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(goffh), 63));
+                    r_msk = lane == k ? tm : r_msk;
+                    r_off = lane == 2 * k ? tw_ : (lane == 2 * k + 1 ? th_ : r_off);
+                }
+                float* gof = a.goff + (size_t)pix * a.G * P * 2 + (size_t)g * P * 2;
+                float* gmk = a.gmsk + (size_t)pix * a.G * P + (size_t)g * P;
+                if (lane < 2 * P) { if (c0 == 0) gof[lane] = r_off; else gof[lane] += r_off; }      // (same lanes, program order)
+                if (lane < P) { if (c0 == 0) gmk[lane] = r_msk; else gmk[lane] += r_msk; }
             }
             // the pixel's column of S (zeros for a pixel beyond the image) and its grad_output row
             if (c0 == 0) {
@@ -612,14 +641,14 @@ extern "C" int ydl_dcnv3_bwd(int dtype, const void* input, const void* offset, c
     static const int notile = getenv("YDL_DCN_NOTILE") ? atoi(getenv("YDL_DCN_NOTILE")) : 0;
     if (!nowin && !notile && g_dcn_win && g_dcn_tile && kernel_h == 3 && kernel_w == 3 && group_channels % 64 == 0 && stride_h == 1 && stride_w == 1 &&
         dilation_h == 1 && dilation_w == 1 && offset_scale == 1.0f && H_out >= 8 && W_out >= 8 &&
-        (long long)N * group * ((W_out + 7) / 8) * ((H_out + 7) / 8) >= 2ll * ydl_device_cus()) {
+        (g_dcn_tile == 2 || (long long)N * group * ((W_out + 7) / 8) * ((H_out + 7) / 8) >= 2ll * ydl_device_cus())) {
         // (a CTA per tile and group, one per CU: maps with fewer than two rounds of tiles — 20 x 20 at batch 16 — keep the
         //  wave-per-pixel kernels: 145 / 203 us against 244 / 295 us at sigma 0 / 2)
         // 8 x 8 pixel tiles: the scatter into grad_input as S x grad_output on the f32 MFMA (dcnv3_bwd_tile_kernel)
         const int tiles_w = (W_out + 7) / 8, tiles_hw = tiles_w * ((H_out + 7) / 8);
         const long long blocks = (long long)N * group * tiles_hw;
         YDL_CHECK(blocks < (1ll << 31), "too many tiles");
-        const size_t lds = (size_t)(64 * T_CPAD + 64 * T_GOLD + 64 * 28) * sizeof(float);
+        const size_t lds = (size_t)(64 * T_CPAD + 64 * T_GOLD + 64 * 9 * T_REC) * sizeof(float);
         if (dtype == YDL_F32) { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<float>), lds); dcnv3_bwd_tile_kernel<float><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
         else if (dtype == YDL_BF16) { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<bf16_t>), lds); dcnv3_bwd_tile_kernel<bf16_t><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
         else { YDL_SET_MAX_LDS((dcnv3_bwd_tile_kernel<_Float16>), lds); dcnv3_bwd_tile_kernel<_Float16><<<(int)blocks, 1024, lds, st>>>(a, tiles_w, tiles_hw); }
