@@ -14,13 +14,13 @@ python3 bench.py --workload $wl --steps 20 --warmup 5 > gpurun_out/${tag}_bench_
 tail -c 2500 gpurun_out/${tag}_bench_${wl}.log | head -c 600; echo
 rm -rf gpurun_out/${tag}_kt_${wl}
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kt_${wl} -o kt --output-format csv -- \
-    python3 bench.py --workload $wl --eager --no-overlap --no-cpu-baseline --no-roofline --steps 20 --warmup 5 > gpurun_out/${tag}_kt_${wl}.log 2>&1 || exit 1
+    python3 bench.py --workload $wl --eager --no-overlap --no-cpu-baseline --no-roofline --no-parity-leg --steps 20 --warmup 5 > gpurun_out/${tag}_kt_${wl}.log 2>&1 || exit 1
 find gpurun_out/${tag}_kt_${wl} -name "*kernel_stats.csv" | head -1
 if [ "$wl" = "cfg2" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     d=gpurun_out/${tag}_pmc_${c}_${wl}; rm -rf $d
     rocprofv3 --pmc $c -d $d -o p --output-format csv -- \
-        python3 bench.py --workload $wl --eager --no-overlap --no-cpu-baseline --no-roofline --steps 5 --warmup 2 > $d.log 2>&1 || exit 1
+        python3 bench.py --workload $wl --eager --no-overlap --no-cpu-baseline --no-roofline --no-parity-leg --steps 5 --warmup 2 > $d.log 2>&1 || exit 1
     # keep only what the summary needs (the raw CSVs are tens of MB)
     python3 - "$d" "$c" <<'PY'
 import csv, glob, json, sys, collections

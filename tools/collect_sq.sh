@@ -18,7 +18,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   d=gpurun_out/${tag}_sqpass_$i; rm -rf $d
   rocprofv3 --pmc $grp -d $d -o p --output-format csv -- \
-      python3 bench.py --workload $wl --eager --no-overlap --no-cpu-baseline --no-roofline --steps 3 --warmup 2 > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+      python3 bench.py --workload $wl --eager --no-overlap --no-cpu-baseline --no-roofline --no-parity-leg --steps 3 --warmup 2 > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   python3 - "$d" "$out" <<'PY'
 import csv, glob, json, sys, collections
 agg = json.load(open(sys.argv[2]))

@@ -266,7 +266,7 @@ def call(name: str, *args):
         g = ConvGeom(*[getattr(src, f) for f, _ in ConvGeom._fields_])
         g._es = 4 if args[1] == YDL_F32 else 2
         g._both = name == "ydl_conv_bwd_pw"          # input AND weight gradient: twice the FLOPs, x + dy + dx + dw bytes
-        g._kernel = last_kernel(1 if "dgrad" in name else 2 if "wgrad" in name else 0)
+        g._kernel = last_kernel(1 if ("dgrad" in name or "bwd_pw" in name) else 2 if "wgrad" in name else 0)
         g._acc = int(args[5]) if "dgrad" in name else int(args[6]) if name.startswith("ydl_conv_fwd") else int(args[7]) if g._both else 0
     elif name == "ydl_bn_act_fwd":          # algorithmic bytes: y (+ residual) read once, out written once
         es = 4 if args[0] == YDL_F32 else 2
