@@ -111,6 +111,9 @@ TILED = [
     ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
     # one channel block: the single-patch-buffer form (four CTAs per CU)
     ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
+    # 3x3 / s1 over ONE 64-channel block, >= 131 072 pixels, image width a multiple of 32: weights in registers (igemm2w_kernel, round 5)
+    ("k3_64x64_wreg_bf16", "bf16", 8, 64, 64, 3, 1, 160, 160, ("igemm2w_kernel<64>", "igemm2w_kernel<64>", "wgrad3_kernel<64>", "")),
+    ("k3_64x128_wreg_bf16", "bf16", 6, 64, 128, 3, 1, 152, 160, ("igemm2w_kernel<128>", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
     # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
     ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,2>", "wgrad3_kernel<128>", "")),
     ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2s_kernel<128,64,2>", "wgrad3_kernel<128>", "")),
@@ -311,7 +314,9 @@ def test_parity_mode_weight_gradient_is_bitwise_reproducible():
     assert ka["wgrad"].startswith("wgrad3_kernel")
     assert torch.equal(a["dw"], b["dw"])
     c, _r, _kc = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
-    assert rel_err(c["dw"], a["dw"]) < 1e-4
+    # (the throughput-mode forward of this layer is the weights-in-registers kernel, whose BatchNorm statistics are those of the STORED
+    #  bf16 values — the tensor that is normalised — where the deterministic path sums the f32 accumulators: 2.6e-4 on dw, measured)
+    assert rel_err(c["dw"], a["dw"]) < 6e-4
 
 
 def test_launch_attributes_are_set_per_device():
@@ -485,12 +490,14 @@ def test_dgrad_with_fused_bn_backward_reduce(case):
     dx_ref = base.clone()
     L.debug_set(8, 0)          # the reference launch on the ring kernel too (the patch-form kernels have no fused epilogue)
     L.debug_set(9, 0)
+    L.debug_set(17, 0)         # (nor has the weights-in-registers kernel)
     try:
         L.call("ydl_conv_dgrad", gp, L.YDL_BF16, P(dy), P(wt), P(dx_ref), acc, st)
         plain = L.last_kernel(1)
     finally:
         L.debug_set(8, 1)
         L.debug_set(9, 1)
+        L.debug_set(17, 1)
     red = L.BnRed()
     red.nseg = len(segs)
     keep = []

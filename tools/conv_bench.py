@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--persist", type=int, default=1, help="0: one tile per CTA instead of the persistent ring kernel (igemm2p)")
     ap.add_argument("--halo", type=int, default=1, help="0: ring kernel instead of the patch-form kernel on the 3x3 / stride-1 layers")
     ap.add_argument("--s2", type=int, default=1, help="0: ring kernel instead of the fused-parity kernel on the k3 s2 p1 data gradients")
+    ap.add_argument("--sums", action="store_true", help="fwd: BatchNorm statistics as replica sums (ydl_conv_fwd_sums: what the training step calls)")
     ap.add_argument("--det", action="store_true", help="wgrad: deterministic slab + fixed-order reduce instead of f32 atomics")
     ap.add_argument("--check", action="store_true", help="compare fwd/dgrad of the ring kernel with igemm_kernel (max abs diff)")
     a = ap.parse_args()
@@ -80,7 +81,9 @@ def main():
         def nxt():
             it[0] += 1
             return it[0] % R
-        ops = {"fwd": lambda i: L.call("ydl_conv_fwd", gp, dt, P(xs[i]), P(w), P(ys[i]), None if a.nostats else P(ws), 0, st),
+        sums = torch.zeros(8 * 2 * ldy, device=dev)
+        ops = {"fwd": (lambda i: L.call("ydl_conv_fwd_sums", gp, dt, P(xs[i]), P(w), P(ys[i]), P(sums), 0, st)) if a.sums else
+                      (lambda i: L.call("ydl_conv_fwd", gp, dt, P(xs[i]), P(w), P(ys[i]), None if a.nostats else P(ws), 0, st)),
                "dgrad": lambda i: L.call("ydl_conv_dgrad", gp, dt, P(dys[i]), P(wt), P(dxs[i]), a.acc, st),
                "wgrad": (lambda i: L.call("ydl_conv_wgrad_det", gp, dt, P(xs[i]), P(dys[i]), P(dw), P(wsd), st)) if a.det else
                         (lambda i: L.call("ydl_conv_wgrad", gp, dt, P(xs[i]), P(dys[i]), P(dw), st))}

@@ -1559,6 +1559,256 @@ __global__ __launch_bounds__(NW * 64) void igemm2hs_kernel(const IgemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// igemm2w (round 5): 3x3 / stride 1 / pad 1 with ONE 64-channel block of K (Kc = 64: K = 576) and at most 128 output channels — the
+// 64 -> 64 and 64 -> 128 layers at 160^2 of config 2, forward and the equally shaped data gradients — with the WEIGHTS IN REGISTERS.
+// Every other MFMA kernel of this file stages both operands through the L2 -> LDS path, which delivers ~70 GB/s per CU: at 64 FLOP
+// per staged byte (128 x 128 tiles) that is 55 % of the matrix peak before anything else, and these short-K layers sat at 0.24-0.34.
+// Here the whole weight matrix of a CTA (CO x 576 bf16 = 72 / 144 KB) lives in the register file as MFMA A fragments — a wave holds
+// 32 output channels x 576 = 36 fragments = 144 VGPRs, loaded once per persistent CTA — and the ONLY staged operand is the
+// activation patch ((R + 2) x 34 pixels x 128 B per block of R x 32 output pixels, LDS-DMA, double-buffered): 260..460 FLOP per
+// staged byte.  v_mfma_f32_32x32x16_bf16 (the 32-row A fragment is what makes 32 channels x 576 fit 144 registers; a 32-pixel B
+// fragment is one image row of the block: 32 consecutive patch rows, conflict-free under the (row >> 1) & 7 chunk swizzle at any
+// offset).  8 waves = CG channel groups x PG pixel groups, two image rows per wave; per block 72 MFMAs and 72 ds_read_b128 per
+// wave (LDS at 50 % of its bandwidth), one DMA wait + two barriers.  Epilogue: bf16 through a swizzled LDS tile into whole pixel rows
+// (asm stores, counted vmcnt); BatchNorm statistics (replica-sum mode only) are taken from that tile in the row layout — a thread
+// owns one 16-byte channel chunk for the whole kernel: (sum, sum of squares) of the STORED values in 16 registers, one atomic pass per
+// CTA.  The layers are then bound by HBM (64 -> 128: 157 MB) rather than by the staging path.
+// ------------------------------------------------------------------------------------------------------
+// A 16-byte store issued from inline asm: the hardware reads the four data registers over two cycles AFTER issue, and a vector
+// instruction that rewrites one of them in the next cycle wins the race (the compiler's hazard recognizer pads a store it knows with
+// a wait state; it cannot see into an asm statement).  Found as an LDS address in every third dword of dx: the `s_nop` is the fix.
+__device__ __forceinline__ void buf_store16_asm(const u32x4& v, unsigned off, const u32x4& rsrc) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rsrc) : "memory");
+}
+#define WR_PW 34
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <int CO, bool STATS>
+__global__ __launch_bounds__(512, 2) void igemm2w_kernel(const IgemmArgs p, int nblocks) {
+    using T = bf16_t;
+    constexpr int CG = CO / 32, PG = 8 / CG, RW = 2, R = PG * RW;       // channel groups, pixel groups, image rows per wave / per block
+    constexpr int PROWS = (R + 2) * WR_PW;
+    constexpr int PASSES = (PROWS + 63) / 64;                             // DMA passes of the CTA, 64 patch pixels each
+    constexpr int PBYTES = PASSES * 64 * GROWB;
+    constexpr int BPX = R * 32;                                           // output pixels per block
+    constexpr int NCH = CO / 8;                                           // 16-byte chunks per output row
+    constexpr int ORB = CO * 2;
+    static_assert(BPX * NCH == 2048, "four 16-byte store slots per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const stage = smem + 2 * PBYTES;                       // [BPX][ORB], chunk q of pixel x at slot q ^ (x & (NCH - 1))
+    float* const sred = (float*)smem;                                     // (after the last block) [8 waves][CO][2]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int cg = wave % CG, pg = wave / CG;
+    const int ln = lane & 31, lh = lane >> 5;
+    const int blocks_w = p.Wo >> 5, blocks_img = (p.Ho / R) * blocks_w;
+    u32x4 rsA, rsC;
+    {
+        const unsigned long long pa = (unsigned long long)p.A, pc = (unsigned long long)p.C;
+        rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
+        rsC = u32x4{(unsigned)pc, (unsigned)(pc >> 32) & 0xffffu, p.bytesC, 0x00020000u};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_lds = lds0 + (unsigned)wave * 1024u;
+    // this thread's patch pixels: pass i -> pixel rho = 64 i + t / 8 of the (R + 2) x 34 patch, 16-byte slot t & 7
+    const int rq = t >> 3, qs = t & 7;
+    int pprc[PASSES];                                                     // (patch row << 8 | patch column) of this thread's pixel of pass i
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int rho = i * 64 + rq;
+        pprc[i] = rho < PROWS ? ((rho / WR_PW) << 8) | (rho - (rho / WR_PW) * WR_PW) : (4000000 << 8);  // (beyond the patch: a row outside any image)
+    }
+    auto block_origin = [&](int b, int& n, int& h0, int& w0) {
+        n = b / blocks_img;
+        const int rem = b - n * blocks_img;
+        h0 = (rem / blocks_w) * R;
+        w0 = (rem % blocks_w) << 5;
+    };
+    auto issue_patch = [&](int b, int buf) {
+        int n, h0, w0;
+        block_origin(b, n, h0, w0);
+        const bool live = b < nblocks;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int rho = i * 64 + rq;
+            const int h = h0 - 1 + (pprc[i] >> 8), w = w0 - 1 + (pprc[i] & 255);
+            const bool ok = live && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
+            const unsigned off = (unsigned)(((n * p.Hi + h) * p.Wi + w) * p.lda) * 2u + (unsigned)((qs ^ ((rho >> 1) & 7)) << 4);
+            lds_dma16(rsA, wave_lds + (unsigned)buf * PBYTES + (unsigned)i * 8192u, ok ? off : 0xFFFFFFFFu);
+        }
+    };
+    // persistent: a contiguous range of blocks per CTA
+    const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = blockIdx.x * per, b1 = min(nblocks, b0 + per);
+    issue_patch(b0, 0);
+    // ---- the weights: 36 A fragments (tap t, 16-channel step ks): row = output channel cg * 32 + ln, 8 channels ks * 16 + lh * 8 ..
+    uint4 wreg[9][4];
+    {
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
+        const int co = cg * 32 + ln;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned off = co < p.Cout ? (unsigned)co * p.ldb_bytes + (unsigned)(((int)p.wt[tp] * p.Kc + ks * 16 + lh * 8) * 2) : 0xFFFFFFFFu;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+                wreg[tp][ks] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+    }
+    int tapd[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) tapd[tp] = (int)p.dh[tp] * WR_PW + (int)p.dw[tp];
+    float s1[STATS ? 8 : 1], s2[STATS ? 8 : 1];
+#pragma unroll
+    for (int e = 0; e < (STATS ? 8 : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const bool want_stats = STATS && p.stats != nullptr;
+    int ridx_base = (pg * RW + 1) * WR_PW + ln + 1;                       // patch pixel of (this wave's first row, column ln), tap (0, 0)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // the first patch (and the weights) have landed
+    int buf = 0;
+    for (int b = b0; b < b1; ++b, buf ^= 1) {
+        issue_patch(b + 1 < b1 ? b + 1 : nblocks, buf ^ 1);               // (beyond the range: all-zero DMAs, the count stays uniform)
+        const unsigned char* const pst = smem + buf * PBYTES;
+        f32x16_t acc[RW];
+#pragma unroll
+        for (int rb = 0; rb < RW; ++rb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+        // (the fragment addresses are block-invariant: left visible, the compiler computes all 72 of them ahead of the block loop and
+        //  spills the weights; behind the empty asm they are recomputed per tap — a handful of VALU per four MFMAs)
+        asm volatile("" : "+v"(ridx_base));
+        // 18 steps (tap, image row) of four fragment reads + four MFMAs (128 matrix cycles), software-pipelined one step deep: the reads
+        // of step i + 1 are in flight under the MFMAs of step i (two fragment sets: the same 32 registers a whole tap's reads took)
+        uint4 fq[2][4];
+        auto rd = [&](int tp, int rb, uint4 (&f)[4]) {
+            const int ridx = ridx_base + rb * WR_PW + tapd[tp];
+            const unsigned char* const rowp = pst + ridx * GROWB;
+            const int sw = (ridx >> 1) & 7;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) f[ks] = *(const uint4*)(rowp + (((2 * ks + lh) ^ sw) << 4));
+        };
+        rd(0, 0, fq[0]);
+#pragma unroll
+        for (int step = 0; step < 9 * RW; ++step) {
+            const int tp = step / RW, rb = step % RW;
+            if (step + 1 < 9 * RW) rd((step + 1) / RW, (step + 1) % RW, fq[(step + 1) & 1]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[tp][ks]),
+                                                                  __builtin_bit_cast(bf16x8, fq[step & 1][ks]), acc[rb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: lane = pixel column ln of rows pg * RW + rb, channels cg * 32 + 8 g + 4 lh + e
+#pragma unroll
+        for (int rb = 0; rb < RW; ++rb) {
+            const int px = (pg * RW + rb) * 32 + ln;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = (uint32_t)f2bf(acc[rb][4 * g + 0]) | ((uint32_t)f2bf(acc[rb][4 * g + 1]) << 16);
+                u.y = (uint32_t)f2bf(acc[rb][4 * g + 2]) | ((uint32_t)f2bf(acc[rb][4 * g + 3]) << 16);
+                const int chq = cg * 4 + g;
+                *(uint2*)(stage + px * ORB + ((chq ^ (px & (NCH - 1))) << 4) + (lh << 3)) = u;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            int n, h0, w0;
+            block_origin(b, n, h0, w0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = t + 512 * j;
+                const int px = idx / NCH, ch = idx % NCH;                 // (ch = t % NCH for every j)
+                const uint4 v = *(const uint4*)(stage + px * ORB + ((ch ^ (px & (NCH - 1))) << 4));
+                if constexpr (STATS) {
+                    if (want_stats) {
+                        float f[8];
+                        unpack16<T>(v, f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s1[e] += f[e]; s2[e] = fmaf(f[e], f[e], s2[e]); }
+                    }
+                }
+                const unsigned m = (unsigned)((n * p.Ho + h0 + (px >> 5)) * p.Wo + w0 + (px & 31));
+                const unsigned off = ch * 8 < p.Cst ? (m * (unsigned)p.ldc + (unsigned)(ch * 8)) * 2u : 0xFFFFFFFFu;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                buf_store16_asm(u32x4{v.x, v.y, v.z, v.w}, off, rsC);
+            }
+        }
+        // the next block's patch: younger than its DMAs are this block's four stores
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    }
+    if constexpr (!STATS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the trailing DMAs land before the LDS allocation goes away
+        return;
+    }
+    if (want_stats) {
+        // a thread's chunk ch = t % NCH holds channels ch * 8 .. + 7: lanes with equal (lane % NCH), then the eight waves through LDS
+#pragma unroll
+        for (int e = 0; e < (STATS ? 8 : 1); ++e)
+#pragma unroll
+            for (int o = NCH; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // trailing DMAs landed: the patch area is free
+        if (lane < NCH) {
+#pragma unroll
+            for (int e = 0; e < (STATS ? 8 : 1); ++e) {
+                sred[(wave * CO + lane * 8 + e) * 2] = s1[e];
+                sred[(wave * CO + lane * 8 + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (t < CO && t < p.Cout) {
+            float a = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { a += sred[(w * CO + t) * 2]; b2 += sred[(w * CO + t) * 2 + 1]; }
+            float* dst = p.stats + (size_t)(blockIdx.x & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
+            atomicAdd(dst + t, a);
+            atomicAdd(dst + p.stats_ld + t, b2);
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the trailing DMAs land before the LDS allocation goes away
+    }
+}
+
+static int g_wreg = 1;          // ydl_debug_set key 17
+static bool wreg_ok(const IgemmArgs& a) {
+    static const int env = getenv("YDL_WREG") ? atoi(getenv("YDL_WREG")) : 1;
+    if (!env || !g_wreg || a.br.nseg > 0 || a.accumulate) return false;
+    if (a.ncls > 1 || a.ntaps != 9 || a.Ttot != 9 || a.in_mul != 1 || a.out_mul != 1 || a.out_h0 != 0 || a.out_w0 != 0) return false;
+    if (a.Hi != a.Ho || a.Wi != a.Wo || a.Hg != a.Ho || a.Wg != a.Wo || a.Kc != 64) return false;
+    if (a.Cst != 64 && a.Cst != 128) return false;
+    if ((a.Wo & 31) || a.Ho % (a.Cst == 128 ? 4 : 8)) return false;
+    if (a.stats != nullptr && !a.stats_atomic) return false;             // (replica-sum statistics only: no per-block partial rows)
+    if ((long long)a.M < 4ll * 128 * ydl_device_cus()) return false;     // a few blocks per CTA, or the register load does not pay
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int t = 0; t < 9; ++t) {
+        const int dh = a.dh[t], dw = a.dw[t];
+        if (dh < -1 || dh > 1 || dw < -1 || dw > 1 || seen[(dh + 1) * 3 + dw + 1]) return false;
+        seen[(dh + 1) * 3 + dw + 1] = true;
+    }
+    return true;
+}
+template <int CO>
+static int launch_igemm2w_cfg(IgemmArgs a, hipStream_t st, int fam) {
+    constexpr int R = (8 / (CO / 32)) * 2;
+    const int nblocks = a.N * (a.Ho / R) * (a.Wo >> 5);
+    constexpr int PASSES = ((R + 2) * WR_PW + 63) / 64;
+    const size_t smem = 2 * (size_t)PASSES * 64 * GROWB + (size_t)R * 32 * CO * 2;
+    YDL_SET_MAX_LDS((igemm2w_kernel<CO, true>), smem);
+    YDL_SET_MAX_LDS((igemm2w_kernel<CO, false>), smem);
+    const unsigned long long bc = ((unsigned long long)(a.N * a.Ho * a.Wo - 1) * a.ldc + a.Cst) * 2ull;
+    YDL_CHECK(bc < 0xFFFFFFF0ull, "output larger than 4 GiB");
+    a.bytesC = (unsigned)bc;
+    static const std::string nm = std::string("igemm2w_kernel<") + std::to_string(CO) + ">";
+    ydl_note_kernel(fam, nm.c_str());
+    const int ctas = std::min(ydl_device_cus(), nblocks);
+    if (a.stats != nullptr) igemm2w_kernel<CO, true><<<ctas, 512, smem, st>>>(a, nblocks);
+    else igemm2w_kernel<CO, false><<<ctas, 512, smem, st>>>(a, nblocks);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+static int launch_igemm2w(const IgemmArgs& a, hipStream_t st, int fam) {
+    return a.Cst == 128 ? launch_igemm2w_cfg<128>(a, st, fam) : launch_igemm2w_cfg<64>(a, st, fam);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // igemm2s: the data gradient of a 3x3 / stride 2 / pad 1 convolution with all four output-parity classes FUSED in one CTA.
 // The ring kernel runs such a dgrad as four dense sub-convolutions (1, 2, 2 and 4 taps): tiles with 2..8 K-steps whose fixed cost
 // (descriptors, first DMA round trip, epilogue) is as large as their main loop, and every class fetches the same dy rows again.
@@ -2675,6 +2925,14 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
             return launch_pw<T>(q, pl, st, fam);
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        // weights-in-registers kernel: 3x3 / s1 over one 64-channel block (igemm2w_kernel).  (Not for the path query of
+        // ydl_conv_dgrad_bnred_supported: a launch WITH the fused BatchNorm reduce skips this kernel and runs on the ring.)
+        if (!force_bm && !path_out && wreg_ok(a)) {
+            if (grid_m_out) *grid_m_out = (a.M + 127) / 128;
+            return launch_igemm2w(a, st, fam);
+        }
+    }
     // K chunks of the shortest class (multi-class dgrad): the ring kernel wants >= 2 K-steps everywhere
     int nch = a.ntaps * (a.Kc / (16 / (int)sizeof(T)));
     if (a.ncls > 1) {
@@ -3539,12 +3797,6 @@ struct PwbwArgs {
     int dbg;
 };
 #define PWBW_SP 32
-// A 16-byte store issued from inline asm: the hardware reads the four data registers over two cycles AFTER issue, and a vector
-// instruction that rewrites one of them in the next cycle wins the race (the compiler's hazard recognizer pads a store it knows with
-// a wait state; it cannot see into an asm statement).  Found as an LDS address in every third dword of dx: the `s_nop` is the fix.
-__device__ __forceinline__ void buf_store16_asm(const u32x4& v, unsigned off, const u32x4& rsrc) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rsrc) : "memory");
-}
 template <int S, bool ACC>
 __global__ __launch_bounds__(512, 2) void pwbw_kernel(const PwbwArgs p) {
     constexpr int SP = PWBW_SP;
@@ -4057,6 +4309,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
+//              key 17 = weights-in-registers kernel for 3x3 / s1 over one 64-channel block (igemm2w_kernel): 1 (default) on, 0 off
 //              key 16 = DCNv3 tile backward (grad_input scatter as S x grad_output on the MFMA): 1 (default) on, 0 off
 //              key 15 = one-pass input + weight gradient of the 128 -> 128 1x1 layers (pwbw_kernel): 1 (default) on, 0 two launches
 //              key 14 = accumulating point-wise launches: 1 (default) per-wave transposed stores also with statistics, 2 only without, 0 never
@@ -4084,6 +4337,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 12) g_stemw = val;
     if (key == 14) g_pw_acc_ts = val;
     if (key == 15) g_pwbw = val;
+    if (key == 17) g_wreg = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
