@@ -320,7 +320,11 @@ def main():
             print(f"[bench] launch-list recording unavailable on rank {rank}: {e!r}", file=sys.stderr)
             torch.cuda.synchronize()
         if not agree([failed])[0]:
+            rstep.host_run_s = rstep.host_launch_s = rstep.host_finish_s = 0.0
             t_replay = quick_ms(rstep.step)
+            if world > 1 and rank == 0:        # where a replayed data-parallel step spends its host time (rehearsal diagnostics)
+                print(f"[bench] replayed step, host ms/step over 6 steps: list segments {rstep.host_run_s / 6 * 1e3:.2f}, bucket launches "
+                      f"{rstep.host_launch_s / 6 * 1e3:.2f}, wait for the buckets {rstep.host_finish_s / 6 * 1e3:.2f}", file=sys.stderr)
         gstep, t_graph = None, BIG
         if args.try_hipgraph:
             failed = 0.0

@@ -1582,20 +1582,23 @@ __device__ __forceinline__ void buf_store16_asm(const u32x4& v, unsigned off, co
 }
 #define WR_PW 34
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-template <int CO, bool STATS>
-__global__ __launch_bounds__(512, 2) void igemm2w_kernel(const IgemmArgs p, int nblocks) {
+// NW = 8: one CTA per CU, its two waves per SIMD in lock-step; NW = 4: half the pixel rows per CTA, two CTAs per CU that drift apart
+// (one's epilogue and DMA issue under the other's MFMAs — the pairing the 128 x 128 ring kernels rely on)
+template <int CO, bool STATS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void igemm2w_kernel(const IgemmArgs p, int nblocks) {
     using T = bf16_t;
-    constexpr int CG = CO / 32, PG = 8 / CG, RW = 2, R = PG * RW;       // channel groups, pixel groups, image rows per wave / per block
+    constexpr int CG = CO / 32, PG = NW / CG, RW = 2, R = PG * RW;      // channel groups, pixel groups, image rows per wave / per block
+    constexpr int NT = NW * 64, PR = NW * 8;                              // threads; patch pixels per DMA pass
     constexpr int PROWS = (R + 2) * WR_PW;
-    constexpr int PASSES = (PROWS + 63) / 64;                             // DMA passes of the CTA, 64 patch pixels each
-    constexpr int PBYTES = PASSES * 64 * GROWB;
+    constexpr int PASSES = (PROWS + PR - 1) / PR;                         // DMA passes of the CTA
+    constexpr int PBYTES = PASSES * PR * GROWB;
     constexpr int BPX = R * 32;                                           // output pixels per block
     constexpr int NCH = CO / 8;                                           // 16-byte chunks per output row
     constexpr int ORB = CO * 2;
-    static_assert(BPX * NCH == 2048, "four 16-byte store slots per thread");
+    static_assert(BPX * NCH == 4 * NT && NT % NCH == 0, "four 16-byte store slots per thread, a fixed channel chunk per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const stage = smem + 2 * PBYTES;                       // [BPX][ORB], chunk q of pixel x at slot q ^ (x & (NCH - 1))
-    float* const sred = (float*)smem;                                     // (after the last block) [8 waves][CO][2]
+    float* const sred = (float*)smem;                                     // (after the last block) [NW waves][CO][2]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int cg = wave % CG, pg = wave / CG;
@@ -1609,12 +1612,12 @@ __global__ __launch_bounds__(512, 2) void igemm2w_kernel(const IgemmArgs p, int 
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned wave_lds = lds0 + (unsigned)wave * 1024u;
-    // this thread's patch pixels: pass i -> pixel rho = 64 i + t / 8 of the (R + 2) x 34 patch, 16-byte slot t & 7
+    // this thread's patch pixels: pass i -> pixel rho = PR i + t / 8 of the (R + 2) x 34 patch, 16-byte slot t & 7
     const int rq = t >> 3, qs = t & 7;
     int pprc[PASSES];                                                     // (patch row << 8 | patch column) of this thread's pixel of pass i
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
-        const int rho = i * 64 + rq;
+        const int rho = i * PR + rq;
         pprc[i] = rho < PROWS ? ((rho / WR_PW) << 8) | (rho - (rho / WR_PW) * WR_PW) : (4000000 << 8);  // (beyond the patch: a row outside any image)
     }
     auto block_origin = [&](int b, int& n, int& h0, int& w0) {
@@ -1629,11 +1632,11 @@ __global__ __launch_bounds__(512, 2) void igemm2w_kernel(const IgemmArgs p, int 
         const bool live = b < nblocks;
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            const int rho = i * 64 + rq;
+            const int rho = i * PR + rq;
             const int h = h0 - 1 + (pprc[i] >> 8), w = w0 - 1 + (pprc[i] & 255);
             const bool ok = live && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
             const unsigned off = (unsigned)(((n * p.Hi + h) * p.Wi + w) * p.lda) * 2u + (unsigned)((qs ^ ((rho >> 1) & 7)) << 4);
-            lds_dma16(rsA, wave_lds + (unsigned)buf * PBYTES + (unsigned)i * 8192u, ok ? off : 0xFFFFFFFFu);
+            lds_dma16(rsA, wave_lds + (unsigned)buf * PBYTES + (unsigned)(i * PR * GROWB), ok ? off : 0xFFFFFFFFu);
         }
     };
     // persistent: a contiguous range of blocks per CTA
@@ -1715,7 +1718,7 @@ __global__ __launch_bounds__(512, 2) void igemm2w_kernel(const IgemmArgs p, int 
             block_origin(b, n, h0, w0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int idx = t + 512 * j;
+                const int idx = t + NT * j;
                 const int px = idx / NCH, ch = idx % NCH;                 // (ch = t % NCH for every j)
                 const uint4 v = *(const uint4*)(stage + px * ORB + ((ch ^ (px & (NCH - 1))) << 4));
                 if constexpr (STATS) {
@@ -1740,7 +1743,7 @@ __global__ __launch_bounds__(512, 2) void igemm2w_kernel(const IgemmArgs p, int 
         return;
     }
     if (want_stats) {
-        // a thread's chunk ch = t % NCH holds channels ch * 8 .. + 7: lanes with equal (lane % NCH), then the eight waves through LDS
+        // a thread's chunk ch = t % NCH holds channels ch * 8 .. + 7: lanes with equal (lane % NCH), then the CTA's waves through LDS
 #pragma unroll
         for (int e = 0; e < (STATS ? 8 : 1); ++e)
 #pragma unroll
@@ -1757,7 +1760,7 @@ __global__ __launch_bounds__(512, 2) void igemm2w_kernel(const IgemmArgs p, int 
         if (t < CO && t < p.Cout) {
             float a = 0.f, b2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) { a += sred[(w * CO + t) * 2]; b2 += sred[(w * CO + t) * 2 + 1]; }
+            for (int w = 0; w < NW; ++w) { a += sred[(w * CO + t) * 2]; b2 += sred[(w * CO + t) * 2 + 1]; }
             float* dst = p.stats + (size_t)(blockIdx.x & (YDL_BN_REPLICAS - 1)) * 2 * p.stats_ld;
             atomicAdd(dst + t, a);
             atomicAdd(dst + p.stats_ld + t, b2);
@@ -1774,7 +1777,7 @@ static bool wreg_ok(const IgemmArgs& a) {
     if (a.ncls > 1 || a.ntaps != 9 || a.Ttot != 9 || a.in_mul != 1 || a.out_mul != 1 || a.out_h0 != 0 || a.out_w0 != 0) return false;
     if (a.Hi != a.Ho || a.Wi != a.Wo || a.Hg != a.Ho || a.Wg != a.Wo || a.Kc != 64) return false;
     if (a.Cst != 64 && a.Cst != 128) return false;
-    if ((a.Wo & 31) || a.Ho % (a.Cst == 128 ? 4 : 8)) return false;
+    if ((a.Wo & 31) || a.Ho % (a.Cst == 128 ? 4 : 8)) return false;      // (blocks of 4 / 8 image rows x 32 columns; the 4-wave form: 2 / 4)
     if (a.stats != nullptr && !a.stats_atomic) return false;             // (replica-sum statistics only: no per-block partial rows)
     if ((long long)a.M < 4ll * 128 * ydl_device_cus()) return false;     // a few blocks per CTA, or the register load does not pay
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
@@ -1785,27 +1788,29 @@ static bool wreg_ok(const IgemmArgs& a) {
     }
     return true;
 }
-template <int CO>
+template <int CO, int NW>
 static int launch_igemm2w_cfg(IgemmArgs a, hipStream_t st, int fam) {
-    constexpr int R = (8 / (CO / 32)) * 2;
+    constexpr int R = (NW / (CO / 32)) * 2, PR = NW * 8;
     const int nblocks = a.N * (a.Ho / R) * (a.Wo >> 5);
-    constexpr int PASSES = ((R + 2) * WR_PW + 63) / 64;
-    const size_t smem = 2 * (size_t)PASSES * 64 * GROWB + (size_t)R * 32 * CO * 2;
-    YDL_SET_MAX_LDS((igemm2w_kernel<CO, true>), smem);
-    YDL_SET_MAX_LDS((igemm2w_kernel<CO, false>), smem);
+    constexpr int PASSES = ((R + 2) * WR_PW + PR - 1) / PR;
+    const size_t smem = 2 * (size_t)PASSES * PR * GROWB + (size_t)R * 32 * CO * 2;
+    YDL_SET_MAX_LDS((igemm2w_kernel<CO, true, NW>), smem);
+    YDL_SET_MAX_LDS((igemm2w_kernel<CO, false, NW>), smem);
     const unsigned long long bc = ((unsigned long long)(a.N * a.Ho * a.Wo - 1) * a.ldc + a.Cst) * 2ull;
     YDL_CHECK(bc < 0xFFFFFFF0ull, "output larger than 4 GiB");
     a.bytesC = (unsigned)bc;
-    static const std::string nm = std::string("igemm2w_kernel<") + std::to_string(CO) + ">";
+    static const std::string nm = std::string("igemm2w_kernel<") + std::to_string(CO) + (NW == 8 ? ">" : ",nw4>");
     ydl_note_kernel(fam, nm.c_str());
-    const int ctas = std::min(ydl_device_cus(), nblocks);
-    if (a.stats != nullptr) igemm2w_kernel<CO, true><<<ctas, 512, smem, st>>>(a, nblocks);
-    else igemm2w_kernel<CO, false><<<ctas, 512, smem, st>>>(a, nblocks);
+    const int ctas = std::min(ydl_device_cus() * (NW == 8 ? 1 : 2), nblocks);
+    if (a.stats != nullptr) igemm2w_kernel<CO, true, NW><<<ctas, NW * 64, smem, st>>>(a, nblocks);
+    else igemm2w_kernel<CO, false, NW><<<ctas, NW * 64, smem, st>>>(a, nblocks);
     YDL_LAUNCH_CHECK();
     return 0;
 }
 static int launch_igemm2w(const IgemmArgs& a, hipStream_t st, int fam) {
-    return a.Cst == 128 ? launch_igemm2w_cfg<128>(a, st, fam) : launch_igemm2w_cfg<64>(a, st, fam);
+    static const int nw = getenv("YDL_WREG_NW") ? atoi(getenv("YDL_WREG_NW")) : 8;       // tuning: 4 = two 4-wave CTAs per CU
+    if (nw == 4) return a.Cst == 128 ? launch_igemm2w_cfg<128, 4>(a, st, fam) : launch_igemm2w_cfg<64, 4>(a, st, fam);
+    return a.Cst == 128 ? launch_igemm2w_cfg<128, 8>(a, st, fam) : launch_igemm2w_cfg<64, 8>(a, st, fam);
 }
 
 // ------------------------------------------------------------------------------------------------------

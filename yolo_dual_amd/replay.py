@@ -188,6 +188,8 @@ class ReplayedTrainStep:
         self._nbt_per_replay = [bn._nbt_pending - a for bn, a in zip(self._bns, nbt0)]
         self._runs_tab = getattr(optimizer, "_runs_dev", None)      # the recorded list holds the raw pointer of this table: keep it alive
         self.host_run_s = 0.0
+        self.host_launch_s = 0.0          # data parallel: host time inside the bucket launches between the segments ...
+        self.host_finish_s = 0.0          # ... and inside the wait for the in-flight buckets at the end of backward
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------
@@ -264,13 +266,17 @@ class ReplayedTrainStep:
                 t0 = pc()
                 self.rec.run(pos, cut)
                 self.host_run_s += pc() - t0
+                t0 = pc()
                 with torch.cuda.stream(st):
                     red._launch(bi)                    # overlaps with the remaining segments
+                self.host_launch_s += pc() - t0
                 pos = cut
             t0 = pc()
             self.rec.run(pos, self._n_fb)
             self.host_run_s += pc() - t0
+            t0 = pc()
             scale = self.dp.finish()
+            self.host_finish_s += pc() - t0
             self.opt.prepare_step(scale)               # H2D of {lr, momentum, wd, scale, EMA decay} on the CURRENT stream ...
             if foreign:
                 self.main.wait_stream(cur)             # ... which the optimizer segment on the main slot must see
