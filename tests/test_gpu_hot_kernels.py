@@ -112,8 +112,8 @@ TILED = [
     # one channel block: the single-patch-buffer form (four CTAs per CU)
     ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
     # 3x3 / s1 over ONE 64-channel block, >= 131 072 pixels, image width a multiple of 32: weights in registers (igemm2w_kernel, round 5)
-    ("k3_64x64_wreg_bf16", "bf16", 8, 64, 64, 3, 1, 160, 160, ("igemm2w_kernel<64>", "igemm2w_kernel<64>", "wgrad3_kernel<64>", "")),
-    ("k3_64x128_wreg_bf16", "bf16", 6, 64, 128, 3, 1, 152, 160, ("igemm2w_kernel<128>", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
+    ("k3_64x64_wreg_bf16", "bf16", 8, 64, 64, 3, 1, 160, 160, ("igemm2w_kernel<64,nw4>", "igemm2w_kernel<64,nw4>", "wgrad3_kernel<64>", "")),
+    ("k3_64x128_wreg_bf16", "bf16", 6, 64, 128, 3, 1, 152, 160, ("igemm2w_kernel<128,nw4>", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
     # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
     ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,2>", "wgrad3_kernel<128>", "")),
     ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2s_kernel<128,64,2>", "wgrad3_kernel<128>", "")),
