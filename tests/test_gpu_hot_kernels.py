@@ -101,31 +101,31 @@ TILED = [
     # sized to one wave of CTAs; 1x1 layers: the 64x64-tile kernel)
     # (>= 128 output channels and Cin % 64 == 0: the LDS-DMA ring kernel igemm2; otherwise igemm_kernel)
     # 3x3 / stride 1 with the image a multiple of 8 x 16: the patch-form kernel (activation patch loaded once per channel block)
-    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2h_kernel<128,128,2>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<128>", "")),
+    ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2h_kernel<128,128,2>", "igemm2h_kernel<128,128,2>", "wgrad3s_kernel<128>", "")),
     # ... the same layer on a 152 x 152 image (not a multiple of 16): the ring kernel
-    ("k3_128x128_ring_bf16", "bf16", 4, 128, 128, 3, 1, 152, 152, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3_kernel<128>", "")),
+    ("k3_128x128_ring_bf16", "bf16", 4, 128, 128, 3, 1, 152, 152, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3s_kernel<128>", "")),
     # ... at 3 x 128 x 128 (192 tiles of 128 x 128, 96 of 256 x 128): too few tiles for the one-CTA-per-CU form, the 128 x 128 / 64 x 128 ring
     ("k3_128x128_ring_small_bf16", "bf16", 3, 128, 128, 3, 1, 120, 136, ("igemm2_kernel<", "igemm2_kernel<", "", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
-    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3_kernel<64>", "")),
-    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<64>", "")),
+    ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3s_kernel<64>", "")),
+    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3s_kernel<64>", "")),
     # one channel block: the single-patch-buffer form (four CTAs per CU)
-    ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
+    ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3s_kernel<64>", "")),
     # 3x3 / s1 over ONE 64-channel block, >= 131 072 pixels, image width a multiple of 32: weights in registers (igemm2w_kernel, round 5)
-    ("k3_64x64_wreg_bf16", "bf16", 8, 64, 64, 3, 1, 160, 160, ("igemm2w_kernel<64,nw4>", "igemm2w_kernel<64,nw4>", "wgrad3_kernel<64>", "")),
-    ("k3_64x128_wreg_bf16", "bf16", 6, 64, 128, 3, 1, 152, 160, ("igemm2w_kernel<128,nw4>", "igemm2h_kernel<128,64,3>", "wgrad3_kernel<128>", "")),
+    ("k3_64x64_wreg_bf16", "bf16", 8, 64, 64, 3, 1, 160, 160, ("igemm2w_kernel<64,nw4>", "igemm2w_kernel<64,nw4>", "wgrad3s_kernel<64>", "")),
+    ("k3_64x128_wreg_bf16", "bf16", 6, 64, 128, 3, 1, 152, 160, ("igemm2w_kernel<128,nw4>", "igemm2h_kernel<128,64,3>", "wgrad3s_kernel<128>", "")),
     # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
-    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,2>", "wgrad3_kernel<128>", "")),
-    ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2s_kernel<128,64,2>", "wgrad3_kernel<128>", "")),
+    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
+    ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
     # ... a dy grid of 88 x 88 (not a multiple of 16): the ring kernel, one launch over the four classes
     ("k3s2_64_128_ring_bf16", "bf16", 8, 64, 128, 3, 2, 176, 176, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
-    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,2>", "wgrad3_kernel<64>", "")),
+    ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,2>", "wgrad3s_kernel<64>", "")),
     # (forward: 400 tiles of 256 x 128, 36 K-steps: the staggered one-CTA-per-CU form; the strided dgrad's parity classes stay on 128 x 128)
-    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<128,128,8,4,2>", "wgrad3_kernel<128>", "")),
+    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<128,128,8,4,2>", "wgrad3s_kernel<128>", "")),
     # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
-    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3_kernel<128>", "")),
-    ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad_kernel<bf16,tr>", "")),
+    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3s_kernel<128>", "")),
+    ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3s_kernel<128>", "")),
     # 12 -> 64 channels, 3x3 / s1 on a 16-channel-stride input: the thin-input kernel of the space-to-depth stem
     # (its weight gradient: the patch-form stemw_kernel from 65 536 pixels and image widths that are multiples of 64)
     ("stem_12_64_bf16", "bf16", 4, 12, 64, 3, 1, 320, 320, ("stem_kernel<bf16,16,64>", "", "stemw_kernel", "")),
@@ -133,7 +133,7 @@ TILED = [
     # ... 13 images of 50 x 128: two 64-pixel segments per row, a stage count (1300) that no CTA count divides
     ("stem_12_64_ragged_bf16", "bf16", 13, 12, 64, 3, 1, 50, 128, ("stem_kernel<bf16,16,64>", "", "stemw_kernel", "")),
     # ragged: 150 output channels (two channel tiles, the second one partial), odd image size, pixel tail
-    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad3_kernel<128>", "")),
+    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad3s_kernel<128>", "")),
 ]
 
 
@@ -175,10 +175,10 @@ def test_pointwise_streaming_kernel_against_oracle(case):
     _check(got, ref, mode, tag)
 
 
-@pytest.mark.parametrize("c1,c2,k,expk", [(128, 128, 1, "pwbw_kernel<128,128>"), (128, 64, 3, "wgrad3_kernel<64>"),
-                                          (64, 128, 3, "wgrad3_kernel<128>"), (128, 128, 1, "wgrad3_kernel<128>")])
+@pytest.mark.parametrize("c1,c2,k,expk", [(128, 128, 1, "pwbw_kernel<128,128>"), (128, 64, 3, "wgrad3s_kernel<64>"),
+                                          (64, 128, 3, "wgrad3s_kernel<128>"), (128, 128, 1, "wgrad3s_kernel<128>")])
 def test_wgrad2_pipelined_kernel_against_oracle(c1, c2, k, expk):
-    """bf16, M = 8*160*160 = 204 800 >= 200 000 pixels: the 128-wide weight-gradient kernel (LDS-DMA feed, wgrad3_kernel); the
+    """bf16, M = 8*160*160 = 204 800 >= 200 000 pixels: the 128-wide weight-gradient kernel (LDS-DMA feed, four loader waves: wgrad3s_kernel); the
     128 -> 128 1x1 layer as the model runs it — input and weight gradient from ONE pass over dy (pwbw_kernel, round 5) — and with
     that switched off (ydl_debug_set key 15): the separate weight-gradient launch"""
     from yolo_dual_amd import _lib as L
@@ -311,7 +311,7 @@ def test_parity_mode_weight_gradient_is_bitwise_reproducible():
         b, _r, _kb = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
     finally:
         config.set_deterministic(None)
-    assert ka["wgrad"].startswith("wgrad3_kernel")
+    assert ka["wgrad"].startswith("wgrad3s_kernel")
     assert torch.equal(a["dw"], b["dw"])
     c, _r, _kc = _case("bf16", 8, 64, 64, 3, 1, 160, 160, seed=4)
     # (the throughput-mode forward of this layer is the weights-in-registers kernel, whose BatchNorm statistics are those of the STORED
@@ -398,21 +398,25 @@ def test_bn_replica_sums_in_blocks_against_the_deterministic_path():
 @pytest.mark.parametrize("shape", [(8, 128, 128, 1, 1, 160), (8, 128, 64, 3, 1, 160), (4, 64, 128, 3, 2, 320), (16, 256, 512, 3, 2, 80),
                                    (3, 64, 152, 3, 1, 83)])
 def test_wgrad_lds_dma_feed_equals_register_staged_kernel(shape):
-    """wgrad3_kernel (operands DMA'd straight into the swizzled LDS image) against wgrad2_kernel (global -> registers -> ds_write):
-    same tiles, same stage order, same MFMA chains — in the deterministic slab form the two are equal bit for bit, on 256-byte and
-    128-byte dY rows, stride 2, pixel tails and a partial channel tile"""
+    """three feeds of the same tile: wgrad3s_kernel (four loader waves DMA the operands straight into the swizzled LDS image, the
+    other four only multiply — the default), wgrad3_kernel (every wave loads and multiplies; one, two loader waves as well) and
+    wgrad2_kernel (global -> registers -> ds_write): same tiles, same stage order, same MFMA chains — in the deterministic slab form all
+    are equal bit for bit, on 256-byte and 128-byte dY rows, stride 2, pixel tails and a partial channel tile"""
     from yolo_dual_amd import _lib as L
     N, c1, c2, k, s_, H = shape
     res = []
     try:
-        for dma in (1, 0):
+        for dma, loaders in ((1, 4), (1, 0), (1, 2), (1, 1), (0, 0)):
             L.debug_set(4, dma)
+            L.debug_set(18, loaders)
             got, _ref, kern = _case("bf16", N, c1, c2, k, s_, H, H, seed=5, deterministic=True)
-            assert kern["wgrad"].startswith("wgrad3_kernel" if dma else "wgrad2_kernel"), kern
+            assert kern["wgrad"].startswith(("wgrad3s_kernel" if loaders else "wgrad3_kernel") if dma else "wgrad2_kernel"), kern
             res.append(got["dw"])
     finally:
         L.debug_set(4, 1)
-    assert torch.equal(res[0], res[1]), rel_err(res[0], res[1])
+        L.debug_set(18, -1)
+    for r in res[1:]:
+        assert torch.equal(res[0], r), rel_err(res[0], r)
 
 
 @pytest.mark.parametrize("dtype,N,C,H,W,k", [("bf16", 3, 72, 20, 20, 5), ("f32", 2, 20, 13, 17, 5), ("bf16", 2, 16, 9, 31, 3),

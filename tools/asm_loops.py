@@ -32,6 +32,11 @@ def classify(op):
         return "wait"
     if op.startswith("s_barrier"):
         return "barrier"
+    # quarter-rate vector instructions (16 cycles per wave instead of 4): 32-bit integer multiplies, the 64-bit multiply-add the
+    # compiler uses for every `a * b + c` on ints, f64 and transcendentals.  A loop whose MFMA count is N x 16 cycles per wave can be
+    # VALU-bound on a handful of these (round 5: wgrad3's per-DMA address arithmetic — 10 of them per stage — cost more than its MFMAs)
+    if re.match(r"v_(mul_lo_u32|mul_hi_u32|mul_hi_i32|mad_u64_u32|mad_i64_i32|exp_|log_|rcp_|rsq_|sqrt_|sin_|cos_|.*_f64)", op):
+        return "valu_slow"
     if op.startswith("v_"):
         return "valu"
     if op.startswith("s_"):
@@ -104,6 +109,9 @@ def main():
                 shown = True
             print(f"   loop @{ls}-{le} ({le - ls} lines): " + " ".join(f"{k}={v}" for k, v in sorted(cnt.items())))
             print(f"      waits: {waits}")
+            mf, vs, vf = cnt.get("mfma", 0), cnt.get("valu_slow", 0), cnt.get("valu", 0)
+            # (16 cycles per 16x16x32 / 32 per 32x32x16 matrix instruction is not told apart here: the estimate uses 16)
+            print(f"      vector-ALU cycles per wave and iteration ~ {4 * vf + 16 * vs} (of which quarter-rate {16 * vs}) against ~{16 * mf} matrix cycles")
             if vm_in_loop:
                 print(f"      !! register-destination VMEM loads inside the loop: {vm_in_loop}")
             if a.dump:

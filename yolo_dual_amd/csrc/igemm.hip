@@ -2680,7 +2680,7 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
     const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int) + (RED ? BN * 16 : 0);
     static const std::string nm = std::string("igemm2_kernel<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
                                   std::to_string(NW) + "," + std::to_string(WP) + "," + std::to_string(S) + (RED ? ",bnred>" : (STG ? ",stg>" : ">"));
-    if constexpr (S == 2 && STG == 0) {
+    if constexpr (S == 2 && STG == 0 && BN == 128) {
         // persistent form (igemm2p_kernel): worth it when a CTA gets more than one tile; needs n_k >= 2 in every class
         static const int persist = getenv("YDL_RING_PERSIST") ? atoi(getenv("YDL_RING_PERSIST")) : 1;
         const int spt = a.Kc >> 6;
@@ -2715,8 +2715,8 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256, 256, 256, 256, 256};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256, 256, 128};
 // patch-form 3x3 / stride-1 kernel (igemm2h_kernel): eligibility and launch
 static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
 static bool halo_ok(const IgemmArgs& a, int id) {
@@ -2846,6 +2846,9 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         case 17: return launch_igemm2<128, 128, 8, 4, 2, false, 2>(a, st, fam);   // staggered + s_setprio 1 for the younger half
         case 18: return launch_igemm2<256, 128, 8, 4, 3, false, 2>(a, st, fam);
         case 19: return launch_igemm2<256, 128, 8, 4, 3, false, 3>(a, st, fam);   // timing experiment: 32x32x16 MFMAs (garbage results)
+        // (ids 20-22: 256 x 256 tiles — 8 waves of 64 x 128 spill ~600 VGPRs at the 256-register budget of two waves per SIMD, 4 waves of
+        //  128 x 128 spill 521 even with 256 AGPRs: not kept)
+        case 23: return launch_igemm2<256, 128, 4, 2, 3>(a, st, fam);             // 256x128, FOUR waves of 128x64 (one per SIMD), 144 KB: measured 15..40 % slower than id 15
     }
     ydl_set_error("internal: unknown ring kernel id");
     return 1;
@@ -3274,39 +3277,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     // range-checked buffer loads (zeros for padding taps / tail rows).  The (image, row, column) of this thread's two pixels are
     // decoded once by multiply-shift and then carried from stage to stage (stages are loaded in order, WG_BKP pixels apart): the two
     // divisions per load were a third of this kernel's VALU instructions (10 per MFMA, round-4 SQ counters)
-    int xn[2], xho[2], xwo[2];
+    // ... and so are the two BYTE OFFSETS (round 5): both are linear in (image, row, column), so a stage step is one add plus a
+    // correction at each wrap instead of six 32-bit multiply-adds per pixel (measured neutral: this kernel is not VALU-bound)
+    int xho[2], xwo[2];
+    unsigned xoff[2], yoff[2];
+    auto x_offset = [&](int n, int ho, int wo) {
+        return (unsigned)(((n * p.Hi + ho * p.s + dh) * p.Wi + wo * p.s + dw) * p.ldx + cc) * (unsigned)sizeof(T);
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const unsigned m = (unsigned)(pbeg + r + 32 * i);
         const unsigned n = fastdiv40(m, p.magicHW);
         const unsigned rem = m - n * (unsigned)HoWo;
         const unsigned ho = fastdiv40(rem, p.magicW);
-        xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+        xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+        xoff[i] = x_offset((int)n, xho[i], xwo[i]);
+        yoff[i] = (unsigned)((int)m * p.ldy + co_chunk) * (unsigned)sizeof(T);
     }
     const int adv_h = WG_BKP / p.Wo, adv_w = WG_BKP - adv_h * p.Wo;
     const bool slow_decode = adv_h + 1 > p.Ho;           // maps narrower than a stage is long: decode by division every time
+    const unsigned adv_step = (unsigned)(((adv_h * p.s) * p.Wi + adv_w * p.s) * p.ldx) * (unsigned)sizeof(T);     // WG_BKP pixels on
+    const unsigned adv_wrap_w = (unsigned)((p.s * p.Wi - p.Wo * p.s) * p.ldx) * (unsigned)sizeof(T);               // one row down, Wo columns back
+    const unsigned adv_wrap_h = (unsigned)(((p.Hi - p.Ho * p.s) * p.Wi) * p.ldx) * (unsigned)sizeof(T);            // into the next image
+    const unsigned adv_y = (unsigned)(WG_BKP * p.ldy) * (unsigned)sizeof(T);
     auto gload = [&](int p0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int m = p0 + r + 32 * i;
             bool in = m < pend;
-            unsigned offy = (in && yv) ? (unsigned)(m * p.ldy + co_chunk) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
-            u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsY, offy, 0, 0);
+            u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsY, (in && yv) ? yoff[i] : 0xFFFFFFFFu, 0, 0);
             vy[i] = make_uint4(a.x, a.y, a.z, a.w);
+            yoff[i] += adv_y;
             if (slow_decode) {
                 const unsigned n = fastdiv40((unsigned)m, p.magicHW);
                 const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
                 const unsigned ho = fastdiv40(rem, p.magicW);
-                xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+                xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+                xoff[i] = x_offset((int)n, xho[i], xwo[i]);
             }
-            int ih = xho[i] * p.s + dh, iw = xwo[i] * p.s + dw;
+            int ih = __mul24(xho[i], p.s) + dh, iw = __mul24(xwo[i], p.s) + dw;       // (full-rate 24-bit multiplies: map sides < 2^21, conv_wgrad_impl)
             bool ok = in && qv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            unsigned offx = ok ? (unsigned)(((xn[i] * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
-            u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsX, offx, 0, 0);
+            u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? xoff[i] : 0xFFFFFFFFu, 0, 0);
             vx[i] = make_uint4(b.x, b.y, b.z, b.w);
-            xwo[i] += adv_w; xho[i] += adv_h;
-            if (xwo[i] >= p.Wo) { xwo[i] -= p.Wo; xho[i] += 1; }
-            if (xho[i] >= p.Ho) { xho[i] -= p.Ho; xn[i] += 1; }
+            xwo[i] += adv_w; xho[i] += adv_h; xoff[i] += adv_step;
+            if (xwo[i] >= p.Wo) { xwo[i] -= p.Wo; xho[i] += 1; xoff[i] += adv_wrap_w; }
+            if (xho[i] >= p.Ho) { xho[i] -= p.Ho; xoff[i] += adv_wrap_h; }
         }
     };
     gload(pbeg);
@@ -3654,17 +3669,31 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wgrad2Args p) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int xn[XR], xho[XR], xwo[XR];            // image, output row and column of this thread's XR pixels of the NEXT stage to issue
+    // Output row / column of this thread's XR pixels of the NEXT stage to issue, and the BYTE OFFSET of the tap-shifted input pixel they
+    // read, carried from stage to stage by additions only (stages are issued in order, SP pixels apart).  The offset is linear in
+    // (image, row, column), so a step of SP pixels is one add plus a correction at each wrap; rows / columns outside the image keep a
+    // meaningless offset that the bounds test below never lets through.  (Round 5: replaces four v_mad_u64_u32 and a v_mul_lo_u32 per
+    // DMA.  Measured neutral, +-1 % on every layer: the loop is not bound by the vector ALU either — see wgrad3s_kernel for what it IS
+    // bound by.)
+    int xho[XR], xwo[XR];
+    unsigned xoff[XR];
+    auto x_offset = [&](int n, int ho, int wo) {
+        return (unsigned)(((n * p.Hi + ho * p.s + dh) * p.Wi + wo * p.s + dw) * p.ldx + cc) * 2u;
+    };
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const unsigned m = (unsigned)(pbeg + xr + 16 * i);
         const unsigned n = fastdiv40(m, p.magicHW);
         const unsigned rem = m - n * (unsigned)HoWo;
         const unsigned ho = fastdiv40(rem, p.magicW);
-        xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+        xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+        xoff[i] = x_offset((int)n, xho[i], xwo[i]);
     }
     const int adv_h = SP / p.Wo, adv_w = SP - adv_h * p.Wo;      // (wave-uniform; one conditional wrap each: adv_w < Wo, adv_h + 1 <= Ho)
     const bool slow_decode = adv_h + 1 > p.Ho;
+    const unsigned adv_step = (unsigned)(((adv_h * p.s) * p.Wi + adv_w * p.s) * p.ldx) * 2u;      // SP pixels on
+    const unsigned adv_wrap_w = (unsigned)((p.s * p.Wi - p.Wo * p.s) * p.ldx) * 2u;                // one row down, Wo columns back
+    const unsigned adv_wrap_h = (unsigned)(((p.Hi - p.Ho * p.s) * p.Wi) * p.ldx) * 2u;             // into the next image
     auto issue = [&](int p0, int buf) {
         const unsigned base = (unsigned)buf * (unsigned)STAGE;
         if (p.dbg == 1) return;
@@ -3684,15 +3713,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wgrad2Args p) {
                 const unsigned n = fastdiv40((unsigned)m, p.magicHW);
                 const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
                 const unsigned ho = fastdiv40(rem, p.magicW);
-                xn[i] = (int)n; xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+                xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+                xoff[i] = x_offset((int)n, xho[i], xwo[i]);
             }
-            const int ih = xho[i] * p.s + dh, iw = xwo[i] * p.s + dw;
+            const int ih = __mul24(xho[i], p.s) + dh, iw = __mul24(xwo[i], p.s) + dw;      // (full-rate 24-bit multiplies: map sides < 2^21, conv_wgrad_impl)
             const bool ok = qv && m < pend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            const unsigned off = ok ? (unsigned)(((xn[i] * p.Hi + ih) * p.Wi + iw) * p.ldx + cc) * 2u : 0xFFFFFFFFu;
-            lds_dma16(rsX, wave_x + base + (unsigned)i * 4096u, off);
-            xwo[i] += adv_w; xho[i] += adv_h;
-            if (xwo[i] >= p.Wo) { xwo[i] -= p.Wo; xho[i] += 1; }
-            if (xho[i] >= p.Ho) { xho[i] -= p.Ho; xn[i] += 1; }
+            lds_dma16(rsX, wave_x + base + (unsigned)i * 4096u, p.dbg == 5 ? (unsigned)(m * 256 + xq * 16) : (ok ? xoff[i] : 0xFFFFFFFFu));
+            xwo[i] += adv_w; xho[i] += adv_h; xoff[i] += adv_step;
+            if (xwo[i] >= p.Wo) { xwo[i] -= p.Wo; xho[i] += 1; xoff[i] += adv_wrap_w; }
+            if (xho[i] >= p.Ho) { xho[i] -= p.Ho; xoff[i] += adv_wrap_h; }
         }
     };
     const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
@@ -3739,12 +3768,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wgrad2Args p) {
     for (int p0 = pbeg; p0 < pend; p0 += SP) {
         wait_vm_barrier<L * (S - 2)>();
         issue(p0 + (S - 1) * SP, nxt);
-        if (p.dbg != 3) compute(buf);
+        if (p.dbg < 3) compute(buf);
         buf = buf + 1 == S ? 0 : buf + 1;
         nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
     wait_vm_barrier<0>();                          // the trailing DMAs land before the CTA (and its LDS allocation) goes away
-    if (p.dbg == 2) {
+    if (p.dbg == 2 || p.dbg >= 4) {
         float sink = 0.f;
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -3770,6 +3799,214 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wgrad2Args p) {
                 }
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad3s: wgrad3 with the two jobs of a wave SPLIT over different waves (round 5).  Measured on wgrad3 (YDL_WG3_DBG): the DMA + barrier
+// loop alone takes 45-65 % of the kernel, the MFMA + fragment-read loop alone 40-55 %, and the whole is their SUM — a wave that is
+// held at its LDS-DMA instructions by a full memory pipeline cannot issue its MFMAs, and with one or two waves per SIMD nobody else can.
+// Here waves 0-3 only multiply (fragment reads + MFMAs, no vector-memory instruction in their loop) and NL extra LOADER waves only
+// issue the DMAs of the ring and wait for them: a stalled loader costs no matrix issue slot.  Same LDS images, same ring, same single
+// barrier per stage (every wave takes part):
+//     loaders:    s_waitcnt vmcnt (stage k landed) | s_barrier | issue stage k+S-1          multipliers:   s_barrier | stage k
+// A loader instruction still writes 1 KiB = 4 rows x 256 B (8 x 128 B for the 64-channel dY image) at (wave-uniform M0) + lane * 16; a
+// loader wave owns instruction slots j = lw, lw + NL, ... of each image, so its lanes' rows are j * rows_per_instruction + lane / slots
+// and the row-dependent swizzle makes the lane's logical chunk (=> tap, channel) a function of j: kept per slot.
+// ------------------------------------------------------------------------------------------------------
+template <int TCO, int SP, int S, int NL>
+__global__ __launch_bounds__(256 + 64 * NL, 2) void wgrad3s_kernel(const Wgrad2Args p) {
+    constexpr int WCO = TCO / 64;
+    constexpr int WJ = 4 / WCO;
+    constexpr int JW = 128 / WJ;
+    constexpr int NA = 4;
+    constexpr int NB = JW / 16;
+    constexpr int YCH = TCO / 8;
+    constexpr int YROWB = TCO * 2;
+    constexpr int YBYTES = SP * YROWB, XBYTES = SP * 256, STAGE = YBYTES + XBYTES;
+    constexpr int NYI = YBYTES / 1024, NXI = XBYTES / 1024;        // DMA instructions per stage and image
+    constexpr int RPI_Y = 64 / YCH;                                 // rows one dY instruction covers (4 or 8); an X instruction covers 4
+    static_assert(NYI % NL == 0 && NXI % NL == 0 && S >= 2, "every loader wave issues the same number of DMAs per stage");
+    constexpr int YPL = NYI / NL, XPL = NXI / NL, LPL = YPL + XPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = tile % p.njt, ct = (tile / p.njt) % p.nct, zt = tile / (p.njt * p.nct);
+    const int pbeg = zt * p.chunk;
+    const int pend = min(p.M, pbeg + p.chunk);
+    if (wave >= 4) {
+        // ---------------- loader waves
+        const int lw = wave - 4;
+        const int cpt = p.Kc / 8;
+        const int nchunks = p.ntaps * cpt;
+        const int HoWo = p.Ho * p.Wo;
+        u32x4 rsX, rsY;
+        {
+            const unsigned long long px = (unsigned long long)p.X, py = (unsigned long long)p.dY;
+            rsX = u32x4{(unsigned)px, (unsigned)(px >> 32) & 0xffffu, p.bytesX, 0x00020000u};
+            rsY = u32x4{(unsigned)py, (unsigned)(py >> 32) & 0xffffu, p.bytesY, 0x00020000u};
+        }
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        // dY slots of this lane
+        const int yq = lane % YCH, yrl = lane / YCH;
+        unsigned yoff[YPL];
+        int yrow[YPL];
+        unsigned yvmask = 0;
+#pragma unroll
+        for (int i = 0; i < YPL; ++i) {
+            const int row = (lw + NL * i) * RPI_Y + yrl;
+            const int ylog = (((yq >> 1) ^ w3f<YROWB>(row)) << 1) | (yq & 1);
+            const int co_chunk = ct * TCO + ylog * 8;
+            yrow[i] = row;
+            if (co_chunk < p.Cout) yvmask |= 1u << i;
+            yoff[i] = (unsigned)((pbeg + row) * p.ldy + co_chunk) * 2u;
+        }
+        const unsigned adv_y = (unsigned)(SP * p.ldy) * 2u;
+        // X slots of this lane: (tap, channel chunk) and the running (row, column, byte offset) of its pixel
+        const int xq = lane & 15, xrl = lane >> 4;
+        int xrow[XPL], xdhw[XPL], xho[XPL], xwo[XPL];
+        unsigned xoff[XPL];
+        unsigned xvmask = 0;
+#pragma unroll
+        for (int i = 0; i < XPL; ++i) {
+            const int row = (lw + NL * i) * 4 + xrl;
+            const int xlog = (((xq >> 1) ^ w3f<256>(row)) << 1) | (xq & 1);
+            const int Q = jt * 16 + xlog;
+            const bool qv = Q < nchunks;
+            const int tap = qv ? Q / cpt : 0;
+            const int cc = (Q - tap * cpt) * 8;
+            const int dh = tap / p.k - p.p, dw = tap % p.k - p.p;
+            xrow[i] = row;
+            xdhw[i] = (dh & 0xffff) | (dw << 16);
+            if (qv) xvmask |= 1u << i;
+            const unsigned m = (unsigned)(pbeg + row);
+            const unsigned n = fastdiv40(m, p.magicHW);
+            const unsigned rem = m - n * (unsigned)HoWo;
+            const unsigned ho = fastdiv40(rem, p.magicW);
+            xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+            xoff[i] = (unsigned)((((int)n * p.Hi + xho[i] * p.s + dh) * p.Wi + xwo[i] * p.s + dw) * p.ldx + cc) * 2u;
+        }
+        const int adv_h = SP / p.Wo, adv_w = SP - adv_h * p.Wo;
+        const bool slow_decode = adv_h + 1 > p.Ho;
+        const unsigned adv_step = (unsigned)(((adv_h * p.s) * p.Wi + adv_w * p.s) * p.ldx) * 2u;
+        const unsigned adv_wrap_w = (unsigned)((p.s * p.Wi - p.Wo * p.s) * p.ldx) * 2u;
+        const unsigned adv_wrap_h = (unsigned)(((p.Hi - p.Ho * p.s) * p.Wi) * p.ldx) * 2u;
+        auto issue = [&](int p0, int buf) {
+            const unsigned base = lds0 + (unsigned)buf * (unsigned)STAGE + (unsigned)lw * 1024u;
+#pragma unroll
+            for (int i = 0; i < YPL; ++i) {
+                const int m = p0 + yrow[i];
+                lds_dma16(rsY, base + (unsigned)(NL * i) * 1024u, (((yvmask >> i) & 1u) && m < pend) ? yoff[i] : 0xFFFFFFFFu);
+                yoff[i] += adv_y;
+            }
+#pragma unroll
+            for (int i = 0; i < XPL; ++i) {
+                const int m = p0 + xrow[i];
+                const int dh = (int)(short)(xdhw[i] & 0xffff), dw = xdhw[i] >> 16;
+                if (slow_decode) {                       // maps narrower than a stage is long: decode by division
+                    const unsigned n = fastdiv40((unsigned)m, p.magicHW);
+                    const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+                    const unsigned ho = fastdiv40(rem, p.magicW);
+                    xho[i] = (int)ho; xwo[i] = (int)(rem - ho * (unsigned)p.Wo);
+                    // (channel chunk of the slot: recovered from the carried offset's low part is not possible here: recompute)
+                    const int xlog = (((xq >> 1) ^ w3f<256>(xrow[i])) << 1) | (xq & 1);
+                    const int Q = jt * 16 + xlog;
+                    const int tap = ((xvmask >> i) & 1u) ? Q / cpt : 0;
+                    const int cc = (Q - tap * cpt) * 8;
+                    xoff[i] = (unsigned)((((int)n * p.Hi + xho[i] * p.s + dh) * p.Wi + xwo[i] * p.s + dw) * p.ldx + cc) * 2u;
+                }
+                const int ih = __mul24(xho[i], p.s) + dh, iw = __mul24(xwo[i], p.s) + dw;
+                const bool ok = ((xvmask >> i) & 1u) && m < pend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                lds_dma16(rsX, base + (unsigned)YBYTES + (unsigned)(NL * i) * 1024u, ok ? xoff[i] : 0xFFFFFFFFu);
+                xwo[i] += adv_w; xho[i] += adv_h; xoff[i] += adv_step;
+                if (xwo[i] >= p.Wo) { xwo[i] -= p.Wo; xho[i] += 1; xoff[i] += adv_wrap_w; }
+                if (xho[i] >= p.Ho) { xho[i] -= p.Ho; xoff[i] += adv_wrap_h; }
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < S - 1; ++u) issue(pbeg + u * SP, u);
+        int nxt = S - 1;
+        for (int p0 = pbeg; p0 < pend; p0 += SP) {
+            wait_vm_barrier<LPL * (S - 2)>();          // this wave's DMAs of stage k have landed; the multipliers are done with stage k-1
+            issue(p0 + (S - 1) * SP, nxt);
+            nxt = nxt + 1 == S ? 0 : nxt + 1;
+        }
+        wait_vm_barrier<0>();                          // the trailing DMAs land before the CTA's LDS goes away
+        return;
+    }
+    // ---------------- multiplier waves
+    const int wi = wave / WJ, wj = wave % WJ;
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    auto compute = [&](int cur) {
+        const unsigned char* by = smem + cur * STAGE;
+        const unsigned char* bx = by + YBYTES;
+#pragma unroll
+        for (int ks = 0; ks < SP / 32; ++ks) {
+            uint4 af[NA], bfv[NB];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int row = ks * 32 + g * 8 + lq;
+                const unsigned char* lo_p = by + w3sw<YROWB>(row, (wi * 64 + a * 16 + lp * 4) * 2);
+                const unsigned char* hi_p = by + w3sw<YROWB>(row + 4, (wi * 64 + a * 16 + lp * 4) * 2);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                af[a] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = ks * 32 + g * 8 + lq;
+                const unsigned char* lo_p = bx + w3sw<256>(row, (wj * JW + b * 16 + lp * 4) * 2);
+                const unsigned char* hi_p = bx + w3sw<256>(row + 4, (wj * JW + b * 16 + lp * 4) * 2);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                bfv[b] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) Mma<bf16_t>::run(af[a], bfv[b], acc[a][b]);
+        }
+    };
+    int buf = 0;
+    for (int p0 = pbeg; p0 < pend; p0 += SP) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this wave holds stage k-1 in registers; stage k is in LDS
+        compute(buf);
+        buf = buf + 1 == S ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (pairs with the loaders' last barrier)
+    const size_t wrow = (size_t)p.ntaps * p.Kc;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            int j = jt * 128 + wj * JW + b * 16 + (lane & 15);
+            if (j < (int)wrow) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int co = ct * TCO + wi * 64 + a * 16 + (lane >> 4) * 4 + e;
+                    if (co < p.Cout) {
+                        if (p.slab) p.slab[((size_t)zt * p.Cout + co) * wrow + j] = acc[a][b][e];
+                        else atomicAdd(p.dW + (size_t)co * p.ldw + j, acc[a][b][e]);
+                    }
+                }
+            }
+        }
+}
+
+template <int TCO, int SP, int S, int NL>
+static int launch_wgrad3s(const Wgrad2Args& a, dim3 grid, hipStream_t st) {
+    const size_t smem = (size_t)S * (SP * (TCO * 2) + SP * 256);
+    YDL_SET_MAX_LDS((wgrad3s_kernel<TCO, SP, S, NL>), smem);
+    wgrad3s_kernel<TCO, SP, S, NL><<<grid, 256 + 64 * NL, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int TCO, int SP, int S>
@@ -4207,6 +4444,12 @@ struct WgradPlan { int kind;     // 0: wgrad_kernel<float>, 1: wgrad_kernel<bf16
                    int jtiles, ctiles, splits, chunk; };
 
 static int g_wgrad_tr = 1;
+static int g_wg3_loaders = -1;   // ydl_debug_set key 18: loader waves of the LDS-DMA weight-gradient kernel (-1: YDL_WG3_LOADERS or 4; 0 off)
+static int wg3_loaders() {
+    static const int env = getenv("YDL_WG3_LOADERS") ? atoi(getenv("YDL_WG3_LOADERS")) : 4;
+    const int v = g_wg3_loaders >= 0 ? g_wg3_loaders : env;
+    return (v == 1 || v == 2 || v == 4) ? v : 0;
+}
 static int g_wgrad_dma = 1;      // 128-wide weight-gradient kernel: 1 = LDS-DMA feed (wgrad3_kernel), 0 = register-staged (wgrad2_kernel)
 
 static WgradPlan wgrad_plan(const ydl_conv_geom* g, int dtype) {
@@ -4231,7 +4474,11 @@ static WgradPlan wgrad_plan(const ydl_conv_geom* g, int dtype) {
         const long sp = slots / tiles;
         mid = sp >= 1 && tiles * sp >= minfill && (M + 63) / 64 >= 4 * sp && (ntaps > 1 || onewave == 2);
     }
-    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && (M >= wg2_min_m || mid)) {
+    // Round 5: with loader waves the 128-wide kernel also wins on the small-map layers that carry enough work (measured against the
+    // 64 x 64-tile kernel, same box: 512->1024 k3s2 @20^2 134 -> 108 us, 2048->1024 @20^2 71 -> 52, 768->128 @80^2 59 -> 53, 512->512 @40^2
+    // 35.1 -> 33.5, 1024->1024 @20^2 34.2 -> 32.6; loses below ~13 GFLOP: 128->256 @80^2 25 -> 36, 256->128 @80^2 25.5 -> 28)
+    const bool heavy = !mid && wg3_loaders() == 4 && g_wgrad_dma && Kc % 8 == 0 && 2.0 * M * (double)g->Cout * ntaps * Kc >= 12.0e9;
+    if (dtype == YDL_BF16 && g_wgrad_tr == 1 && (M >= wg2_min_m || mid || heavy)) {
         const int TCO = g->Cout > 64 ? 128 : 64;
         pl.kind = TCO == 128 ? 4 : 3;
         pl.jtiles = (ntaps * Kc + 127) / 128;
@@ -4316,6 +4563,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
+//              key 18 = loader waves of the LDS-DMA weight-gradient kernel (wgrad3s_kernel): 4 (default) / 2 / 1 loader waves per CTA, 0 = wgrad3_kernel
 //              key 17 = weights-in-registers kernel for 3x3 / s1 over one 64-channel block (igemm2w_kernel): 1 (default) on, 0 off
 //              key 16 = DCNv3 tile backward (grad_input scatter as S x grad_output on the MFMA): 1 (default) on, 0 off
 //              key 15 = one-pass input + weight gradient of the 128 -> 128 1x1 layers (pwbw_kernel): 1 (default) on, 0 two launches
@@ -4345,6 +4593,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 14) g_pw_acc_ts = val;
     if (key == 15) g_pwbw = val;
     if (key == 17) g_wreg = val;
+    if (key == 18) g_wg3_loaders = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
@@ -4366,6 +4615,7 @@ static int conv_wgrad_impl(const ydl_conv_geom* g, int dtype, const void* x, con
     // pixel decode by multiply-shift with magic = ceil(2^40 / d), d <= Ho*Wo: exact for every n <= M while M * d < 2^40
     YDL_CHECK(bx < 0xFFFFFFF0ull && by < 0xFFFFFFF0ull && (unsigned long long)M * ((unsigned long long)g->Ho * g->Wo) < (1ull << 40),
               "tensor too large for the 32-bit wgrad addressing");
+    YDL_CHECK(g->Ho < (1 << 21) && g->Wo < (1 << 21), "map side of 2^21 or more: not supported by the weight-gradient kernels (24-bit row / column arithmetic)");
     const unsigned long long magicW = ((1ull << 40) + g->Wo - 1) / g->Wo;
     const unsigned long long magicHW = ((1ull << 40) + (unsigned long long)g->Ho * g->Wo - 1) / ((unsigned long long)g->Ho * g->Wo);
     const int ldw = g->ldw ? g->ldw : ntaps * Kc;
@@ -4390,6 +4640,14 @@ static int conv_wgrad_impl(const ydl_conv_geom* g, int dtype, const void* x, con
             static const int cfg = getenv("YDL_WG3_CFG") ? atoi(getenv("YDL_WG3_CFG")) : 1;
             ydl_note_kernel(2, pl.kind == 4 ? "wgrad3_kernel<128>" : "wgrad3_kernel<64>");
             int e = 0;
+            // loader-wave form (wgrad3s_kernel): four loader waves per CTA by default (ydl_debug_set key 18 / YDL_WG3_LOADERS = 0: every
+            // wave loads and multiplies, wgrad3_kernel; 1, 2: fewer loader waves — measured slower than no split, 4: -12..-20 % on every layer)
+            const int loaders = wg3_loaders();
+            if (loaders) ydl_note_kernel(2, pl.kind == 4 ? "wgrad3s_kernel<128>" : "wgrad3s_kernel<64>");
+            if (loaders == 1 || loaders == 2 || loaders == 4) {
+                if (pl.kind == 4) e = loaders == 1 ? launch_wgrad3s<128, 32, 4, 1>(a, grid, st) : (loaders == 2 ? launch_wgrad3s<128, 32, 4, 2>(a, grid, st) : launch_wgrad3s<128, 32, 4, 4>(a, grid, st));
+                else e = loaders == 1 ? launch_wgrad3s<64, 32, 4, 1>(a, grid, st) : (loaders == 2 ? launch_wgrad3s<64, 32, 4, 2>(a, grid, st) : launch_wgrad3s<64, 32, 4, 4>(a, grid, st));
+            } else
             if (pl.kind == 4) e = cfg == 0 ? launch_wgrad3<128, 64, 2>(a, grid, st) : (cfg == 2 ? launch_wgrad3<128, 64, 3>(a, grid, st) : launch_wgrad3<128, 32, 4>(a, grid, st));
             else e = cfg == 0 ? launch_wgrad3<64, 64, 2>(a, grid, st) : (cfg == 2 ? launch_wgrad3<64, 64, 3>(a, grid, st) : launch_wgrad3<64, 32, 4>(a, grid, st));
             if (e) return e;
