@@ -103,9 +103,9 @@ TILED = [
     # 3x3 / stride 1 with the image a multiple of 8 x 16: the patch-form kernel (activation patch loaded once per channel block)
     ("k3_128x128_bf16", "bf16", 4, 128, 128, 3, 1, 160, 160, ("igemm2h_kernel<128,128,2>", "igemm2h_kernel<128,128,2>", "wgrad3s_kernel<128>", "")),
     # ... the same layer on a 152 x 152 image (not a multiple of 16): the ring kernel
-    ("k3_128x128_ring_bf16", "bf16", 4, 128, 128, 3, 1, 152, 152, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3s_kernel<128>", "")),
+    ("k3_128x128_ring_bf16", "bf16", 4, 128, 128, 3, 1, 152, 152, ("igemm2l_kernel<256,128,8+4,3>", "igemm2l_kernel<256,128,8+4,3>", "wgrad3s_kernel<128>", "")),
     # ... at 3 x 128 x 128 (192 tiles of 128 x 128, 96 of 256 x 128): too few tiles for the one-CTA-per-CU form, the 128 x 128 / 64 x 128 ring
-    ("k3_128x128_ring_small_bf16", "bf16", 3, 128, 128, 3, 1, 120, 136, ("igemm2_kernel<", "igemm2_kernel<", "", "")),
+    ("k3_128x128_ring_small_bf16", "bf16", 3, 128, 128, 3, 1, 120, 136, ("igemm2l_kernel<256,128,8+4,3>", "igemm2l_kernel<256,128,8+4,3>", "", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
     ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3s_kernel<64>", "")),
     ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3s_kernel<64>", "")),
@@ -116,16 +116,16 @@ TILED = [
     ("k3_64x128_wreg_bf16", "bf16", 6, 64, 128, 3, 1, 152, 160, ("igemm2w_kernel<128,nw4>", "igemm2h_kernel<128,64,3>", "wgrad3s_kernel<128>", "")),
     # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
     ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
-    ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
+    ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2l_kernel<256,128,8+4,3>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
     # ... a dy grid of 88 x 88 (not a multiple of 16): the ring kernel, one launch over the four classes
     ("k3s2_64_128_ring_bf16", "bf16", 8, 64, 128, 3, 2, 176, 176, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
     ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,2>", "wgrad3s_kernel<64>", "")),
     # (forward: 400 tiles of 256 x 128, 36 K-steps: the staggered one-CTA-per-CU form; the strided dgrad's parity classes stay on 128 x 128)
-    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<128,128,8,4,2>", "wgrad3s_kernel<128>", "")),
+    ("k3s2_256_512_bf16", "bf16", 16, 256, 512, 3, 2, 80, 80, ("igemm2l_kernel<256,128,8+4,3>", "igemm2_kernel<128,128,8,4,2>", "wgrad3s_kernel<128>", "")),
     # small grids (< 256 tiles of 128x128): 64-pixel ring tiles; pixel-tile-fastest order for the 4.7 MB weight matrix
-    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2_kernel<64,128,4,2,3>", "igemm2_kernel<64,128,4,2,3>", "wgrad3s_kernel<128>", "")),
-    ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2_kernel<256,128,8,4,3,stg>", "igemm2_kernel<256,128,8,4,3,stg>", "wgrad3s_kernel<128>", "")),
+    ("k3_512_20_bf16", "bf16", 16, 512, 512, 3, 1, 20, 20, ("igemm2l_kernel<128,128,8+4,3>", "igemm2l_kernel<128,128,8+4,3>", "wgrad3s_kernel<128>", "")),
+    ("k1_2048_1024_bf16", "bf16", 16, 2048, 1024, 1, 1, 20, 20, ("igemm2l_kernel<256,128,8+4,3>", "igemm2l_kernel<256,128,8+4,3>", "wgrad3s_kernel<128>", "")),
     # 12 -> 64 channels, 3x3 / s1 on a 16-channel-stride input: the thin-input kernel of the space-to-depth stem
     # (its weight gradient: the patch-form stemw_kernel from 65 536 pixels and image widths that are multiples of 64)
     ("stem_12_64_bf16", "bf16", 4, 12, 64, 3, 1, 320, 320, ("stem_kernel<bf16,16,64>", "", "stemw_kernel", "")),
@@ -395,6 +395,52 @@ def test_bn_replica_sums_in_blocks_against_the_deterministic_path():
         ydl.set_compute_dtype("bf16")
 
 
+@pytest.mark.parametrize("cin,cout,k,N,H,names", [
+    (128, 128, 3, 4, 152, ("igemm2l_kernel<256,128,8+4,3>", "igemm2_kernel<256,128,8,4,3,stg>")),
+    (256, 256, 3, 16, 40, ("igemm2l_kernel<256,128,8+4,3>", "igemm2_kernel<256,128,8,4,3,stg>")),
+    (512, 512, 3, 16, 20, ("igemm2l_kernel<128,128,8+4,3>", "igemm2_kernel<64,128,4,2,3>")),
+    (1024, 2048, 1, 16, 20, ("igemm2l_kernel<256,128,8+4,3>", "igemm2_kernel<256,128,8,4,3,stg>")),
+    (136, 192, 3, 2, 83, ("igemm2l_kernel<128,128,8+4,3>", "igemm2_kernel<64,128,4,2,3>"))])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_loader_wave_ring_kernel_equals_the_plain_ring_kernel(cin, cout, k, N, H, names, accumulate):
+    """igemm2l_kernel (eight waves only multiply, four only issue the LDS-DMA ring: ydl_debug_set key 19) against igemm2_kernel (every
+    wave does both) through ydl_conv_dgrad: the same K-step order into the same accumulators, so the two are equal bit for bit — 3x3
+    tiles with padding taps and pixel tails, a deep 1x1, the small-grid 128 x 128 form, a ragged map with partial channel tiles,
+    overwrite and gradient fan-in — and both against float64 on the same bf16 operands (seg_diceloss_yolov5.py:388-409 backward)"""
+    import ctypes
+    from yolo_dual_amd import _lib as L
+    rs = np.random.RandomState(cin + cout + k)
+    p_ = k // 2
+    dy = torch.from_numpy(rs.standard_normal((N, cout, H, H)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rs.standard_normal((cout, cin, k, k)) / np.sqrt(k * k * cout)).astype(np.float32)).bfloat16()
+    dx0 = torch.from_numpy(rs.standard_normal((N, cin, H, H)).astype(np.float32)).bfloat16()
+    ref = torch.nn.grad.conv2d_input((N, cin, H, H), w.float(), dy.float(), stride=1, padding=p_).double() + (dx0.double() if accumulate else 0.0)
+    dev = torch.device("cuda")
+    dy_g = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    wt_g = w.permute(1, 2, 3, 0).reshape(cin, k * k, cout).contiguous().to(dev)       # [Cin][tap][Cout]
+    g = L.ConvGeom(N, H, H, cin, H, H, cout, k, 1, p_, cin, cout)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    res, kerns = [], []
+    L.debug_set(8, 0)              # (the 3x3 shapes on the ring family, not on the patch-form kernels)
+    try:
+        for on in (1, 0):
+            L.debug_set(19, on)
+            dx_g = dx0.permute(0, 2, 3, 1).contiguous().to(dev)
+            L.call("ydl_conv_dgrad", ctypes.byref(g), L.YDL_BF16, P(dy_g), P(wt_g), P(dx_g), accumulate, st)
+            torch.cuda.synchronize()
+            kerns.append(L.last_kernel(1))
+            res.append(dx_g)
+    finally:
+        L.debug_set(19, -1)
+        L.debug_set(8, 1)
+    if names is not None:
+        assert tuple(kerns) == names, kerns
+    assert torch.equal(res[0], res[1]), rel_err(res[0].float(), res[1].float())
+    got = res[0].float().permute(0, 3, 1, 2).cpu().double()
+    assert l2_err(got, ref) < 4e-3, l2_err(got, ref)
+
+
 @pytest.mark.parametrize("shape", [(8, 128, 128, 1, 1, 160), (8, 128, 64, 3, 1, 160), (4, 64, 128, 3, 2, 320), (16, 256, 512, 3, 2, 80),
                                    (3, 64, 152, 3, 1, 83)])
 def test_wgrad_lds_dma_feed_equals_register_staged_kernel(shape):
@@ -494,7 +540,8 @@ def test_dgrad_with_fused_bn_backward_reduce(case):
     dx_ref = base.clone()
     L.debug_set(8, 0)          # the reference launch on the ring kernel too (the patch-form kernels have no fused epilogue)
     L.debug_set(9, 0)
-    L.debug_set(17, 0)         # (nor has the weights-in-registers kernel)
+    L.debug_set(17, 0)         # (nor has the weights-in-registers kernel, nor the loader-wave ring)
+    L.debug_set(19, 0)
     try:
         L.call("ydl_conv_dgrad", gp, L.YDL_BF16, P(dy), P(wt), P(dx_ref), acc, st)
         plain = L.last_kernel(1)
@@ -502,6 +549,7 @@ def test_dgrad_with_fused_bn_backward_reduce(case):
         L.debug_set(8, 1)
         L.debug_set(9, 1)
         L.debug_set(17, 1)
+        L.debug_set(19, -1)
     red = L.BnRed()
     red.nseg = len(segs)
     keep = []

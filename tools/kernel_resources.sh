@@ -28,8 +28,11 @@ igemm2w_kernelILi128ELb0ELi4E 2 0
 igemm2s_kernelILi8ELi4ELi2ELb0E 4 2
 igemm2s_kernelILi8ELi4ELi2ELb1E 4 2
 igemm2p_kernelILi128ELi128ELi8ELi4ELb0E 4 0
-igemm2p_kernelILi128ELi64ELi8ELi4ELb0E 5 0
 igemm2p_kernelILi128ELi128ELi8ELi4ELb1E 4 1
+igemm2l_kernelILi256ELi128ELi8ELi4ELi3ELi4E 3 0
+igemm2l_kernelILi128ELi128ELi8ELi4ELi3ELi4E 3 0
+wgrad3s_kernelILi128ELi32ELi4ELi4E 4 0
+wgrad3s_kernelILi64ELi32ELi4ELi4E 4 0
 pwbw_kernelILi5ELb0E 5 0
 pwbw_kernelILi4ELb1E 5 0
 wgrad3_kernelILi128E 3 0

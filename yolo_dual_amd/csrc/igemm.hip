@@ -1018,6 +1018,224 @@ __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------------
+// igemm2l: the ring kernel with LOADER WAVES (round 5; the weight gradient's wgrad3s_kernel has the measurements that led here).
+// In igemm2_kernel every wave issues its share of the step's DMAs and then multiplies; the no-DMA / no-MFMA ablations each remove
+// 35-40 % of the time — the two phases ADD: a wave held at its LDS-DMA instructions by a full memory pipeline cannot issue MFMAs.
+// Here NW multiplier waves (waves 0 .. NW-1: fragment reads + MFMAs, no vector-memory instruction in their loop, then the epilogue) and
+// NL loader waves (waves NW ..: tap tables, row descriptors, every DMA of the ring, the counted waits) share ONE s_barrier per K-step:
+//     loaders:      s_waitcnt vmcnt (step k landed) | s_barrier | issue step k+S-1 into the stage step k-1 occupied
+//     multipliers:  ... MFMA(k-1, second half) | lgkmcnt(0) | s_barrier | read(k) | MFMA(k) ...     (software-pipelined as in igemm2)
+// A DMA instruction writes 8 tile rows x 128 B; loader wave lw owns instruction slots j = lw, lw + NL, ... of the A rows and of the B
+// rows, so a lane's rows are 8 j + (lane >> 3): with NL even the swizzle term ((row >> 1) & 7) is the same for all of a lane's slots.
+// The loaders return before the epilogue (s_barrier counts the surviving waves only).
+// ------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NW, int WP, int S, int NL>
+__global__ __launch_bounds__((NW + NL) * 64, S == 2 ? 2 : 1) void igemm2l_kernel(const IgemmArgs p) {
+    using T = bf16_t;
+    constexpr int ES = 2;
+    constexpr int NAI = BM / 8, NBI = BN / 8;          // DMA instructions per K-step: activation rows, weight rows
+    static_assert(NAI % NL == 0 && NBI % NL == 0 && NL % 2 == 0 && S >= 2, "every loader wave issues the same number of DMAs per step");
+    constexpr int APL = NAI / NL, BPL = NBI / NL, LPL = APL + BPL;
+    constexpr int WN = NW / WP;
+    constexpr int BNW = BN / WN;
+    constexpr int CT = BNW / 16;
+    constexpr int PT = BM / (16 * WP);
+    constexpr int STAGE = (BM + BN) * GROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sTapA = (int*)(smem + S * STAGE);
+    int* sTapB = sTapA + MAXTAPS;
+    int* sTapD = sTapB + MAXTAPS;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mtile, ntile;
+    if (p.m_fastest) { ntile = tile / p.grid_m; mtile = tile - ntile * p.grid_m; }
+    else { mtile = tile / p.grid_n; ntile = tile - mtile * p.grid_n; }
+    int c_ntaps = p.ntaps, c_tap0 = 0, c_Hg = p.Hg, c_Wg = p.Wg, c_M = p.M, c_h0 = p.out_h0, c_w0 = p.out_w0;
+    if (p.ncls > 1) {
+        int c = 0;
+        while (c + 1 < p.ncls && mtile >= p.cls_tile0[c + 1]) ++c;
+        mtile -= p.cls_tile0[c];
+        c_ntaps = p.cls_ntaps[c]; c_tap0 = p.cls_tap0[c]; c_Hg = p.cls_Hg[c]; c_Wg = p.cls_Wg[c]; c_M = p.cls_M[c];
+        c_h0 = p.cls_h0[c]; c_w0 = p.cls_w0[c];
+    }
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+    if (t < MAXTAPS) {
+        int da = 0, db = 0, dd = 0;
+        if (t < c_ntaps) {
+            da = ((int)p.dh[c_tap0 + t] * p.Wi + (int)p.dw[c_tap0 + t]) * p.lda * ES;
+            db = (int)p.wt[c_tap0 + t] * p.Kc * ES;
+            dd = ((int)p.dh[c_tap0 + t] & 0xffff) | ((int)p.dw[c_tap0 + t] << 16);
+        }
+        sTapA[t] = da;
+        sTapB[t] = db;
+        sTapD[t] = dd;
+    }
+    __syncthreads();   // tap tables visible (no DMA is in flight yet)
+    const int spt = p.Kc >> 6;
+    const int nk = c_ntaps * spt;
+
+    if (wave >= NW) {
+        // ---------------- loader waves
+        const int lw = wave - NW;
+        const int r8 = lane >> 3, qs = lane & 7;
+        const unsigned q16 = (unsigned)((qs ^ (((r8 >> 1) | ((lw & 1) << 2)) & 7)) << 4);      // (row >> 1) & 7 with row = 8 j + r8, j = lw (mod 2)
+        unsigned rowoff[APL], vmask[APL];
+        {
+            int ih0[APL], iw0[APL];
+#pragma unroll
+            for (int i = 0; i < APL; ++i) {
+                const int m = m0 + (lw + NL * i) * 8 + r8;
+                rowoff[i] = 0;
+                vmask[i] = 0;
+                ih0[i] = -100000;          // tail rows: no tap is valid => zeros
+                iw0[i] = 0;
+                if (m < c_M) {
+                    const int gw = m % c_Wg;
+                    const int tmp = m / c_Wg;
+                    const int gh = tmp % c_Hg;
+                    const int n = tmp / c_Hg;
+                    ih0[i] = gh * p.in_mul;
+                    iw0[i] = gw * p.in_mul;
+                    rowoff[i] = (unsigned)(((n * p.Hi + ih0[i]) * p.Wi + iw0[i]) * p.lda) * (unsigned)ES + q16;
+                }
+            }
+            for (int tp = 0; tp < c_ntaps; ++tp) {            // uniform loop, broadcast LDS reads
+                const int dd = sTapD[tp];
+                const int dh = (int)(short)(dd & 0xffff), dw = dd >> 16;
+#pragma unroll
+                for (int i = 0; i < APL; ++i) {
+                    const bool ok = (unsigned)(ih0[i] + dh) < (unsigned)p.Hi && (unsigned)(iw0[i] + dw) < (unsigned)p.Wi;
+                    vmask[i] |= ok ? (1u << tp) : 0u;
+                }
+            }
+        }
+        unsigned browoff[BPL];
+#pragma unroll
+        for (int i = 0; i < BPL; ++i) {
+            const int co = n0 + (lw + NL * i) * 8 + r8;
+            browoff[i] = co < p.Cout ? (unsigned)co * p.ldb_bytes + q16 : 0xF0000000u;
+        }
+        u32x4 rsA, rsB;
+        {
+            const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+            rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, p.bytesA, 0x00020000u};
+            rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xffffu, p.bytesB, 0x00020000u};
+        }
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const unsigned wave_lds = lds0 + (unsigned)lw * (8 * GROWB);
+        int tap = 0, cb = 0;
+        int nxtA = sTapA[0], nxtB = sTapB[0];
+        auto issue = [&](int stg) {
+            const int da = nxtA, db = nxtB;
+            const bool live = cb < spt;                                // steps beyond the end: every lane out of range
+            const unsigned kb = (unsigned)cb << 7;
+            const unsigned tbit = live ? 1u << tap : 0u;
+            const unsigned kbB = live ? kb : 0xF0000000u;
+            if (++tap == c_ntaps) { tap = 0; ++cb; }
+            nxtA = sTapA[tap];
+            nxtB = sTapB[tap];
+            const unsigned base = wave_lds + (unsigned)stg * STAGE;
+#pragma unroll
+            for (int i = 0; i < APL; ++i)
+                lds_dma16(rsA, base + (unsigned)(NL * i) * (8 * GROWB), (vmask[i] & tbit) ? rowoff[i] + (unsigned)da + kb : 0xFFFFFFFFu);
+#pragma unroll
+            for (int i = 0; i < BPL; ++i)
+                lds_dma16(rsB, base + BM * GROWB + (unsigned)(NL * i) * (8 * GROWB), browoff[i] + (unsigned)db + kbB);
+        };
+#pragma unroll
+        for (int u = 0; u < S - 1; ++u) issue(u);
+        int nxt = S - 1;
+        for (int kk = 0; kk < nk; ++kk) {
+            wait_vm_barrier<LPL * (S - 2)>();          // this wave's DMAs of step kk have landed; the multipliers hold step kk-1 in registers
+            issue(nxt);                                // step kk+S-1 -> the stage step kk-1 occupied
+            nxt = nxt + 1 == S ? 0 : nxt + 1;
+        }
+        wait_vm_barrier<0>();                          // the trailing all-zero DMAs have landed: the epilogue may reuse the LDS
+        return;
+    }
+
+    // ---------------- multiplier waves
+    const int wc = wave % WN, wp = wave / WN;
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lrow = lane & 15;
+    const int sw_rd = (lrow >> 1) & 7;
+    const int lk0 = (((lane >> 4)) ^ sw_rd) << 4;
+    const int lk1 = (((lane >> 4) + 4) ^ sw_rd) << 4;
+    const unsigned char* const fa = smem + BM * GROWB + (wc * BNW + lrow) * GROWB;     // weights  (MFMA A operand)
+    const unsigned char* const fb = smem + (wp * (BM / WP) + lrow) * GROWB;             // pixels   (MFMA B operand)
+    uint4 af0[CT], bf0[PT], af1[CT], bf1[PT];
+    auto rdfrag = [&](int stg, int half, uint4 (&af)[CT], uint4 (&bfr)[PT]) {
+        const unsigned char* a_base = fa + stg * STAGE + (half ? lk1 : lk0);
+        const unsigned char* b_base = fb + stg * STAGE + (half ? lk1 : lk0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) af[c] = *(const uint4*)(a_base + c * 16 * GROWB);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) bfr[j] = *(const uint4*)(b_base + j * 16 * GROWB);
+    };
+    auto mma = [&](const uint4 (&af)[CT], const uint4 (&bfr)[PT]) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
+    };
+    // barrier count: one per K-step (opening it) + the closing one — the same nk + 1 the loaders execute
+    if (nk > 0) {
+        asm volatile("s_barrier" ::: "memory");            // step 0 landed everywhere
+        rdfrag(0, 0, af0, bf0);
+    }
+    int stg = 0;
+    for (int kk = 0; kk < nk; ++kk) {
+        rdfrag(stg, 1, af1, bf1);
+        mma(af0, bf0);
+        stg = stg + 1 == S ? 0 : stg + 1;
+        if (kk + 1 < nk) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this wave holds all of step kk; step kk+1 landed everywhere
+            rdfrag(stg, 0, af0, bf0);
+        }
+        mma(af1, bf1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              // (pairs with the loaders' closing barrier)
+    igemm2_epilogue<BM, BN, NW, WP, false>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0, nullptr);
+}
+
+template <int BM, int BN, int NW, int WP, int S, int NL>
+static int launch_igemm2l(IgemmArgs a, hipStream_t st, int fam) {
+    a.grid_n = (a.Cst + BN - 1) / BN;
+    int mtiles = (a.M + BM - 1) / BM;
+    if (a.ncls > 1) {
+        int acc = 0;
+        for (int c = 0; c < a.ncls; ++c) { a.cls_tile0[c] = acc; acc += (a.cls_M[c] + BM - 1) / BM; }
+        a.cls_tile0[a.ncls] = acc;
+        mtiles = acc;
+    }
+    a.grid_m = mtiles;
+    YDL_CHECK(a.bytesB < 0x08000000u, "ring kernel: weight matrix of 128 MiB or more is not supported");
+    {
+        static const int forced = getenv("YDL_RING_MFAST") ? atoi(getenv("YDL_RING_MFAST")) : -1;
+        const double wbytes = (double)a.Cout * a.Ttot * a.Kc * 2.0;
+        const double abytes = (double)a.N * a.Hi * a.Wi * a.lda * 2.0;
+        a.m_fastest = (wbytes > 2.0e6 && (double)mtiles * wbytes > (double)a.grid_n * abytes) ? 1 : 0;
+        if (forced >= 0) a.m_fastest = forced;
+    }
+    const size_t smem = (size_t)S * (BM + BN) * GROWB + 3 * MAXTAPS * sizeof(int);
+    static const std::string nm = std::string("igemm2l_kernel<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(NW) + "+" +
+                                  std::to_string(NL) + "," + std::to_string(S) + ">";
+    YDL_SET_MAX_LDS((igemm2l_kernel<BM, BN, NW, WP, S, NL>), smem);
+    ydl_note_kernel(fam, nm.c_str());
+    igemm2l_kernel<BM, BN, NW, WP, S, NL><<<dim3(mtiles * a.grid_n), (NW + NL) * 64, smem, st>>>(a);
+    YDL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // igemm2p: the two-stage ring kernel as a PERSISTENT CTA that walks several output tiles, with the ring running across tile
 // boundaries.  In igemm2_kernel a tile costs t0 + n_k t1 with t0 (tap tables, row decode, the first DMA round trip, the epilogue's
 // LDS transpose, stores and statistics) as large as six K-steps; the step issued beyond a tile's last K-step was an all-zero dummy.
@@ -2646,7 +2864,12 @@ static int launch_igemm(IgemmArgs a, hipStream_t st, int fam) {
     return 0;
 }
 
-struct TileCfg { int BM, BN; int ring; };     // ring != 0: igemm2_kernel (bf16 LDS-DMA ring) instantiation id
+struct TileCfg { int BM, BN; int ring; };
+static int g_ring_loaders = -1;   // ydl_debug_set key 19: loader-wave ring kernel where it measured faster (-1: YDL_RING_LOADERS or on)
+static int ring_loaders() {
+    static const int env = getenv("YDL_RING_LOADERS") ? atoi(getenv("YDL_RING_LOADERS")) : 1;
+    return g_ring_loaders >= 0 ? g_ring_loaders : env;
+}     // ring != 0: igemm2_kernel (bf16 LDS-DMA ring) instantiation id
 static int g_ring_enabled = 1;
 static int g_ring_persist = 1;
 
@@ -2715,13 +2938,13 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256, 256, 256, 256, 256};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256, 256, 128};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256, 256, 256, 256, 256, 256, 128, 256, 128};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256, 256, 128, 128, 128, 128, 128};
 // patch-form 3x3 / stride-1 kernel (igemm2h_kernel): eligibility and launch
 static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
 static bool halo_ok(const IgemmArgs& a, int id) {
     static const int env = getenv("YDL_HALO") ? atoi(getenv("YDL_HALO")) : 1;
-    if (!env || !g_halo || (id != 7 && id != 13 && id != 15) || a.br.nseg > 0) return false;
+    if (!env || !g_halo || (id != 7 && id != 13 && id != 15 && id != 24) || a.br.nseg > 0) return false;
     if (a.ncls > 1 || a.ntaps != 9 || a.Ttot != 9 || a.in_mul != 1 || a.out_mul != 1 || a.out_h0 != 0 || a.out_w0 != 0) return false;
     if (a.Hi != a.Ho || a.Wi != a.Wo || a.Hg != a.Ho || a.Wg != a.Wo || (a.Ho & 7) || (a.Wo & 15) || (a.Kc & 63)) return false;
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
@@ -2814,7 +3037,7 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         // weight ring depth: 6 stages x 16 KB + two patches = 144 KB, one CTA per CU with five weight steps in flight; 64-wide tiles
         // 3 stages x 8 KB = 72 KB, two CTAs per CU (YDL_HALO_S: tuning)
         static const int hs = getenv("YDL_HALO_S") ? atoi(getenv("YDL_HALO_S")) : 0;
-        if (id == 7 || id == 15) {
+        if (id == 7 || id == 15 || id == 24) {
             if (hs == 3) return launch_igemm2h<128, 3>(a, st, fam);
             if (hs == 6) return launch_igemm2h<128, 6>(a, st, fam);
             return launch_igemm2h<128, 2>(a, st, fam);
@@ -2848,6 +3071,10 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         case 19: return launch_igemm2<256, 128, 8, 4, 3, false, 3>(a, st, fam);   // timing experiment: 32x32x16 MFMAs (garbage results)
         // (ids 20-22: 256 x 256 tiles — 8 waves of 64 x 128 spill ~600 VGPRs at the 256-register budget of two waves per SIMD, 4 waves of
         //  128 x 128 spill 521 even with 256 AGPRs: not kept)
+        case 24: return launch_igemm2l<256, 128, 8, 4, 3, 4>(a, st, fam);         // loader waves: 8 multipliers of 64x64 + 4 loaders, 144 KB
+        case 25: return launch_igemm2l<128, 128, 8, 4, 3, 4>(a, st, fam);         // 8 multipliers of 32x64 + 4 loaders, 96 KB
+        case 26: return launch_igemm2l<256, 128, 8, 4, 3, 2>(a, st, fam);
+        case 27: return launch_igemm2l<128, 128, 8, 4, 2, 4>(a, st, fam);         // two stages, 64 KB: two CTAs (24 waves) per CU
         case 23: return launch_igemm2<256, 128, 4, 2, 3>(a, st, fam);             // 256x128, FOUR waves of 128x64 (one per SIMD), 144 KB: measured 15..40 % slower than id 15
     }
     ydl_set_error("internal: unknown ring kernel id");
@@ -2855,7 +3082,7 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
 }
 
 // Tile choice: a pure function of (M, Cst, K chunks, dtype) — the stats-workspace queries call it too.
-static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int Kc = 0, int taps = 0, bool one_class = true) {
+static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int Kc = 0, int taps = 0, bool one_class = true, bool loaders_ok = true) {
     TileCfg c;
     c.ring = 0;
     // 64..127 stored output channels: 128x64 tile, 8 waves, 2 stages = 48 KB (three CTAs per CU).  Measured against the register-staged
@@ -2879,6 +3106,16 @@ static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int 
         static const int big = getenv("YDL_RING256") ? atoi(getenv("YDL_RING256")) : 1;
         const long b256 = (long)((M + 255) / 256) * ((Cst + 127) / 128);
         if (big && one_class && Cst >= 128 && b256 >= 180 && b256 <= 512 && nchunks >= 96) id = 15;
+        // Round 5, loader waves (igemm2l_kernel: 8 multiplier + 4 loader waves, one CTA per CU, three stages): where the choice was a
+        // one-CTA-per-CU tile anyway it wins 3..12 % over the staggered 256 x 128 (256->512 k3s2 @40^2 85.7 -> 75.1 us, 256->256 k3 @40^2
+        // 41.0 -> 38.5, 2048->1024 @20^2 35.1 -> 32.4, 512->1024 k3s2 @20^2 65.4 -> 62.0), and as 128 x 128 it replaces the 64 x 128 tile of
+        // the small grids (512->512 k3 @20^2 forward 44.9 -> 37.8 us, dgrad 42.4 -> 35.6; 1024->512 @20^2 15.8 -> 14.1).  The two-CTA
+        // 128 x 128 ring keeps everything else: with 24 waves per CU the split form has 80 registers and loses 10-40 %.
+        // (ydl_debug_set key 19 / YDL_RING_LOADERS=0: off)
+        if (ring_loaders() && loaders_ok) {     // (not for a launch with the fused BatchNorm-backward reduce, nor for its support query)
+            if (id == 15) id = 24;
+            if (id == 9 && b128 >= 64) id = 25;
+        }
         if (Cst < 128) id = ring64;
         if (forced >= 0) id = forced;
         if (id > 0) { c.ring = id; c.BM = kRingBM[id]; c.BN = kRingBN[id]; return c; }
@@ -2949,7 +3186,7 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st, int fam, int* grid
         nch = 1 << 30;
         for (int i = 0; i < a.ncls; ++i) nch = min(nch, a.cls_ntaps[i] * (a.Kc / (16 / (int)sizeof(T))));
     }
-    TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2, a.Kc, a.Ttot, a.ncls <= 1);
+    TileCfg c = pick_cfg(a.M, a.Cst, nch, sizeof(T) == 2, a.Kc, a.Ttot, a.ncls <= 1, a.br.nseg == 0 && path_out == nullptr);
     if constexpr (sizeof(T) == 2) {
         if (c.ring && !force_bm) {
             if (path_out) { *path_out = ring_has_bnred(c.ring) ? 2 : 4; return 0; }
@@ -4563,6 +4800,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //              key 10 = integer-factor bilinear resize backward (resize_bwd_int_kernel): 1 (default) on, 0 generic gather
 //              key 11 = row-walking resize forward: 1 (default) on, 0 element-indexed kernel
 //              key 12 = patch-form weight gradient of the space-to-depth stem (stemw_kernel): 1 (default) on, 0 tiled kernel
+//              key 19 = loader-wave ring kernel (igemm2l_kernel) where pick_cfg prefers it: 1 (default) on, 0 off
 //              key 18 = loader waves of the LDS-DMA weight-gradient kernel (wgrad3s_kernel): 4 (default) / 2 / 1 loader waves per CTA, 0 = wgrad3_kernel
 //              key 17 = weights-in-registers kernel for 3x3 / s1 over one 64-channel block (igemm2w_kernel): 1 (default) on, 0 off
 //              key 16 = DCNv3 tile backward (grad_input scatter as S x grad_output on the MFMA): 1 (default) on, 0 off
@@ -4594,6 +4832,7 @@ extern "C" void ydl_debug_set(int key, int val) {
     if (key == 15) g_pwbw = val;
     if (key == 17) g_wreg = val;
     if (key == 18) g_wg3_loaders = val;
+    if (key == 19) g_ring_loaders = val;
 }
 
 extern "C" int64_t ydl_conv_wgrad_ws_bytes(const ydl_conv_geom* g, int dtype) {
@@ -4644,6 +4883,8 @@ static int conv_wgrad_impl(const ydl_conv_geom* g, int dtype, const void* x, con
             // wave loads and multiplies, wgrad3_kernel; 1, 2: fewer loader waves — measured slower than no split, 4: -12..-20 % on every layer)
             const int loaders = wg3_loaders();
             if (loaders) ydl_note_kernel(2, pl.kind == 4 ? "wgrad3s_kernel<128>" : "wgrad3s_kernel<64>");
+            // (stage shape, measured with four loaders: 32 pixels x 4 stages; 64 x 2 is equal within 3 % either way, 64 x 3 — one CTA per
+            //  CU — loses 10-20 % on the 3x3 layers)
             if (loaders == 1 || loaders == 2 || loaders == 4) {
                 if (pl.kind == 4) e = loaders == 1 ? launch_wgrad3s<128, 32, 4, 1>(a, grid, st) : (loaders == 2 ? launch_wgrad3s<128, 32, 4, 2>(a, grid, st) : launch_wgrad3s<128, 32, 4, 4>(a, grid, st));
                 else e = loaders == 1 ? launch_wgrad3s<64, 32, 4, 1>(a, grid, st) : (loaders == 2 ? launch_wgrad3s<64, 32, 4, 2>(a, grid, st) : launch_wgrad3s<64, 32, 4, 4>(a, grid, st));
