@@ -2938,8 +2938,8 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256, 256, 256, 256, 256, 256, 128, 256, 128};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256, 256, 128, 128, 128, 128, 128};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256, 256, 256, 256, 256, 256, 128, 256, 128, 128};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256, 256, 128, 128, 128, 128, 128, 128};
 // patch-form 3x3 / stride-1 kernel (igemm2h_kernel): eligibility and launch
 static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
 static bool halo_ok(const IgemmArgs& a, int id) {
@@ -3073,8 +3073,8 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         //  128 x 128 spill 521 even with 256 AGPRs: not kept)
         case 24: return launch_igemm2l<256, 128, 8, 4, 3, 4>(a, st, fam);         // loader waves: 8 multipliers of 64x64 + 4 loaders, 144 KB
         case 25: return launch_igemm2l<128, 128, 8, 4, 3, 4>(a, st, fam);         // 8 multipliers of 32x64 + 4 loaders, 96 KB
-        case 26: return launch_igemm2l<256, 128, 8, 4, 3, 2>(a, st, fam);
-        case 27: return launch_igemm2l<128, 128, 8, 4, 2, 4>(a, st, fam);         // two stages, 64 KB: two CTAs (24 waves) per CU
+        // (ids 26-28, measured and dropped — profiles/r5_ab_ring_loader_waves.log: 256 x 128 with two loaders 3..8 % behind four; 128 x 128 with two
+        //  stages and two CTAs per CU: four loaders = 24 waves = 80 registers, two loaders = 16 DMAs per loader and step — both 10..60 % slower)
         case 23: return launch_igemm2<256, 128, 4, 2, 3>(a, st, fam);             // 256x128, FOUR waves of 128x64 (one per SIMD), 144 KB: measured 15..40 % slower than id 15
     }
     ydl_set_error("internal: unknown ring kernel id");
@@ -3113,7 +3113,7 @@ static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int 
         // 128 x 128 ring keeps everything else: with 24 waves per CU the split form has 80 registers and loses 10-40 %.
         // (ydl_debug_set key 19 / YDL_RING_LOADERS=0: off)
         if (ring_loaders() && loaders_ok) {     // (not for a launch with the fused BatchNorm-backward reduce, nor for its support query)
-            if (id == 15) id = 24;
+            if (id == 15 && nchunks >= 128) id = 24;      // (12 K-steps, 768 -> 128 @80^2: 42.8 against 41.2 us — the staggered form keeps it)
             if (id == 9 && b128 >= 64) id = 25;
         }
         if (Cst < 128) id = ring64;
