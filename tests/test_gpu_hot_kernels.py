@@ -108,17 +108,17 @@ TILED = [
     ("k3_128x128_ring_small_bf16", "bf16", 3, 128, 128, 3, 1, 120, 136, ("igemm2l_kernel<256,128,8+4,3>", "igemm2l_kernel<256,128,8+4,3>", "", "")),
     # 64..127 stored output channels: the 128x64 ring tile (three CTAs per CU)
     ("k3_128x64_bf16", "bf16", 4, 128, 64, 3, 1, 160, 160, ("igemm2h_kernel<128,64,3>", "igemm2h_kernel<128,128,2>", "wgrad3s_kernel<64>", "")),
-    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2_kernel<128,128,8,4,2>", "wgrad3s_kernel<64>", "")),
+    ("k3_128x64_ring_bf16", "bf16", 4, 128, 64, 3, 1, 152, 152, ("igemm2_kernel<128,64,8,4,2>", "igemm2l_kernel<128,128,4+4,2>", "wgrad3s_kernel<64>", "")),
     # one channel block: the single-patch-buffer form (four CTAs per CU)
     ("k3_64x64_patch_bf16", "bf16", 8, 64, 64, 3, 1, 96, 160, ("igemm2h_kernel<128,64,2>", "igemm2h_kernel<128,64,2>", "wgrad3s_kernel<64>", "")),
     # 3x3 / s1 over ONE 64-channel block, >= 131 072 pixels, image width a multiple of 32: weights in registers (igemm2w_kernel, round 5)
     ("k3_64x64_wreg_bf16", "bf16", 8, 64, 64, 3, 1, 160, 160, ("igemm2w_kernel<64,nw4>", "igemm2w_kernel<64,nw4>", "wgrad3s_kernel<64>", "")),
     ("k3_64x128_wreg_bf16", "bf16", 6, 64, 128, 3, 1, 152, 160, ("igemm2w_kernel<128,nw4>", "igemm2h_kernel<128,64,3>", "wgrad3s_kernel<128>", "")),
     # k3 s2 p1 data gradient with the dy grid a multiple of 8 x 16: all four output-parity classes fused in one CTA (igemm2s_kernel)
-    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2_kernel<128,128,8,4,2>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
+    ("k3s2_64_128_bf16", "bf16", 4, 64, 128, 3, 2, 320, 320, ("igemm2l_kernel<128,128,4+4,2>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
     ("k3s2_128_256_fused_bf16", "bf16", 4, 128, 256, 3, 2, 160, 160, ("igemm2l_kernel<256,128,8+4,3>", "igemm2s_kernel<128,64,2>", "wgrad3s_kernel<128>", "")),
     # ... a dy grid of 88 x 88 (not a multiple of 16): the ring kernel, one launch over the four classes
-    ("k3s2_64_128_ring_bf16", "bf16", 8, 64, 128, 3, 2, 176, 176, ("igemm2_kernel<128,128,8,4,2>", "igemm2_kernel<128,64,8,4,2>", "", "")),
+    ("k3s2_64_128_ring_bf16", "bf16", 8, 64, 128, 3, 2, 176, 176, ("igemm2l_kernel<128,128,4+4,2>", "igemm2_kernel<128,64,8,4,2>", "", "")),
     # Cin not a multiple of 64: the register-staged kernel; its dgrad (96 output channels, K rows of 64) is ring-eligible
     ("k3_96_64_bf16", "bf16", 4, 96, 64, 3, 1, 160, 160, ("igemm_kernel<bf16,128,64,4", "igemm2h_kernel<128,64,2>", "wgrad3s_kernel<64>", "")),
     # (forward: 400 tiles of 256 x 128, 36 K-steps: the staggered one-CTA-per-CU form; the strided dgrad's parity classes stay on 128 x 128)
@@ -133,7 +133,7 @@ TILED = [
     # ... 13 images of 50 x 128: two 64-pixel segments per row, a stage count (1300) that no CTA count divides
     ("stem_12_64_ragged_bf16", "bf16", 13, 12, 64, 3, 1, 50, 128, ("stem_kernel<bf16,16,64>", "", "stemw_kernel", "")),
     # ragged: 150 output channels (two channel tiles, the second one partial), odd image size, pixel tail
-    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2_kernel<128,128,8,4,2>", "igemm_kernel<bf16,64,64,4", "wgrad3s_kernel<128>", "")),
+    ("k3_ragged_bf16", "bf16", 3, 64, 152, 3, 1, 75, 83, ("igemm2l_kernel<128,128,4+4,2>", "igemm_kernel<bf16,64,64,4", "wgrad3s_kernel<128>", "")),
 ]
 
 
@@ -400,12 +400,15 @@ def test_bn_replica_sums_in_blocks_against_the_deterministic_path():
     (256, 256, 3, 16, 40, ("igemm2l_kernel<256,128,8+4,3>", "igemm2_kernel<256,128,8,4,3,stg>")),
     (512, 512, 3, 16, 20, ("igemm2l_kernel<128,128,8+4,3>", "igemm2_kernel<64,128,4,2,3>")),
     (1024, 2048, 1, 16, 20, ("igemm2l_kernel<256,128,8+4,3>", "igemm2_kernel<256,128,8,4,3,stg>")),
-    (136, 192, 3, 2, 83, ("igemm2l_kernel<128,128,8+4,3>", "igemm2_kernel<64,128,4,2,3>"))])
+    (136, 192, 3, 2, 83, ("igemm2l_kernel<128,128,8+4,3>", "igemm2_kernel<64,128,4,2,3>")),
+    (512, 512, 1, 16, 40, ("igemm2l_kernel<128,128,4+4,2>", "igemm2_kernel<128,128,8,4,2>")),
+    (136, 192, 3, 3, 83, ("igemm2l_kernel<128,128,4+4,2>", "igemm2_kernel<128,128,8,4,2>"))])
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_loader_wave_ring_kernel_equals_the_plain_ring_kernel(cin, cout, k, N, H, names, accumulate):
     """igemm2l_kernel (eight waves only multiply, four only issue the LDS-DMA ring: ydl_debug_set key 19) against igemm2_kernel (every
     wave does both) through ydl_conv_dgrad: the same K-step order into the same accumulators, so the two are equal bit for bit — 3x3
-    tiles with padding taps and pixel tails, a deep 1x1, the small-grid 128 x 128 form, a ragged map with partial channel tiles,
+    tiles with padding taps and pixel tails, a deep 1x1, the small-grid 128 x 128 form, the two-CTA four + four wave form, ragged maps with
+    partial channel tiles,
     overwrite and gradient fan-in — and both against float64 on the same bf16 operands (seg_diceloss_yolov5.py:388-409 backward)"""
     import ctypes
     from yolo_dual_amd import _lib as L

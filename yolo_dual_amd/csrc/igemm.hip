@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(NW * 64, RED ? NW / 2 : 1) void igemm2_kernel(const
 // The loaders return before the epilogue (s_barrier counts the surviving waves only).
 // ------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int NW, int WP, int S, int NL>
-__global__ __launch_bounds__((NW + NL) * 64, S == 2 ? 2 : 1) void igemm2l_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__((NW + NL) * 64, S == 2 ? (NW + NL) / 2 : 1) void igemm2l_kernel(const IgemmArgs p) {      // (2nd argument: waves per SIMD — two CTAs per CU for the two-stage forms)
     using T = bf16_t;
     constexpr int ES = 2;
     constexpr int NAI = BM / 8, NBI = BN / 8;          // DMA instructions per K-step: activation rows, weight rows
@@ -1187,20 +1187,33 @@ __global__ __launch_bounds__((NW + NL) * 64, S == 2 ? 2 : 1) void igemm2l_kernel
             for (int j = 0; j < PT; ++j) Mma<T>::run(af[c], bfr[j], acc[c][j]);
     };
     // barrier count: one per K-step (opening it) + the closing one — the same nk + 1 the loaders execute
-    if (nk > 0) {
-        asm volatile("s_barrier" ::: "memory");            // step 0 landed everywhere
-        rdfrag(0, 0, af0, bf0);
-    }
-    int stg = 0;
-    for (int kk = 0; kk < nk; ++kk) {
-        rdfrag(stg, 1, af1, bf1);
-        mma(af0, bf0);
-        stg = stg + 1 == S ? 0 : stg + 1;
-        if (kk + 1 < nk) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this wave holds all of step kk; step kk+1 landed everywhere
-            rdfrag(stg, 0, af0, bf0);
+    constexpr bool PIPE = NW >= 8;     // 64 x 64 wave tiles of a 4-wave CTA: ONE fragment set (the second costs 32 registers the two-CTA form lacks)
+    if constexpr (PIPE) {
+        if (nk > 0) {
+            asm volatile("s_barrier" ::: "memory");            // step 0 landed everywhere
+            rdfrag(0, 0, af0, bf0);
         }
-        mma(af1, bf1);
+        int stg = 0;
+        for (int kk = 0; kk < nk; ++kk) {
+            rdfrag(stg, 1, af1, bf1);
+            mma(af0, bf0);
+            stg = stg + 1 == S ? 0 : stg + 1;
+            if (kk + 1 < nk) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // this wave holds all of step kk; step kk+1 landed everywhere
+                rdfrag(stg, 0, af0, bf0);
+            }
+            mma(af1, bf1);
+        }
+    } else {
+        int stg = 0;
+        for (int kk = 0; kk < nk; ++kk) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // step kk landed everywhere; this wave is done reading step kk-1
+            rdfrag(stg, 0, af0, bf0);
+            mma(af0, bf0);
+            rdfrag(stg, 1, af0, bf0);
+            mma(af0, bf0);
+            stg = stg + 1 == S ? 0 : stg + 1;
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              // (pairs with the loaders' closing barrier)
     igemm2_epilogue<BM, BN, NW, WP, false>(p, acc, smem, m0, n0, mtile, c_M, c_Wg, c_Hg, c_h0, c_w0, nullptr);
@@ -2938,13 +2951,13 @@ static int launch_igemm2(IgemmArgs a, hipStream_t st, int fam) {
 }
 
 // ring instantiations: id -> (BM, BN)
-static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256, 256, 256, 256, 256, 256, 128, 256, 128, 128};
-static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256, 256, 128, 128, 128, 128, 128, 128};
+static const int kRingBM[] = {0, 256, 128, 128, 256, 128, 128, 128, 128, 64, 64, 128, 128, 128, 128, 256, 256, 128, 256, 256, 256, 256, 256, 256, 256, 128, 256, 128, 128, 128, 128};
+static const int kRingBN[] = {0, 128, 128, 64, 64, 128, 128, 128, 64, 128, 128, 64, 64, 64, 128, 128, 128, 128, 128, 128, 256, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128};
 // patch-form 3x3 / stride-1 kernel (igemm2h_kernel): eligibility and launch
 static int g_halo = 1;          // ydl_debug_set key 8 (YDL_HALO=0 at start-up)
 static bool halo_ok(const IgemmArgs& a, int id) {
     static const int env = getenv("YDL_HALO") ? atoi(getenv("YDL_HALO")) : 1;
-    if (!env || !g_halo || (id != 7 && id != 13 && id != 15 && id != 24) || a.br.nseg > 0) return false;
+    if (!env || !g_halo || (id != 7 && id != 13 && id != 15 && id != 24 && id != 29) || a.br.nseg > 0) return false;
     if (a.ncls > 1 || a.ntaps != 9 || a.Ttot != 9 || a.in_mul != 1 || a.out_mul != 1 || a.out_h0 != 0 || a.out_w0 != 0) return false;
     if (a.Hi != a.Ho || a.Wi != a.Wo || a.Hg != a.Ho || a.Wg != a.Wo || (a.Ho & 7) || (a.Wo & 15) || (a.Kc & 63)) return false;
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
@@ -3037,7 +3050,7 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         // weight ring depth: 6 stages x 16 KB + two patches = 144 KB, one CTA per CU with five weight steps in flight; 64-wide tiles
         // 3 stages x 8 KB = 72 KB, two CTAs per CU (YDL_HALO_S: tuning)
         static const int hs = getenv("YDL_HALO_S") ? atoi(getenv("YDL_HALO_S")) : 0;
-        if (id == 7 || id == 15 || id == 24) {
+        if (id == 7 || id == 15 || id == 24 || id == 29) {
             if (hs == 3) return launch_igemm2h<128, 3>(a, st, fam);
             if (hs == 6) return launch_igemm2h<128, 6>(a, st, fam);
             return launch_igemm2h<128, 2>(a, st, fam);
@@ -3073,6 +3086,7 @@ static int launch_ring(int id, const IgemmArgs& a, hipStream_t st, int fam) {
         //  128 x 128 spill 521 even with 256 AGPRs: not kept)
         case 24: return launch_igemm2l<256, 128, 8, 4, 3, 4>(a, st, fam);         // loader waves: 8 multipliers of 64x64 + 4 loaders, 144 KB
         case 25: return launch_igemm2l<128, 128, 8, 4, 3, 4>(a, st, fam);         // 8 multipliers of 32x64 + 4 loaders, 96 KB
+        case 29: return launch_igemm2l<128, 128, 4, 2, 2, 4>(a, st, fam);         // 4 multipliers of 64x64 + 4 loaders, two stages: two CTAs (16 waves) per CU
         // (ids 26-28, measured and dropped — profiles/r5_ab_ring_loader_waves.log: 256 x 128 with two loaders 3..8 % behind four; 128 x 128 with two
         //  stages and two CTAs per CU: four loaders = 24 waves = 80 registers, two loaders = 16 DMAs per loader and step — both 10..60 % slower)
         case 23: return launch_igemm2<256, 128, 4, 2, 3>(a, st, fam);             // 256x128, FOUR waves of 128x64 (one per SIMD), 144 KB: measured 15..40 % slower than id 15
@@ -3115,6 +3129,11 @@ static TileCfg pick_cfg(int M, int Cst, int nchunks = 0, bool bf16 = false, int 
         if (ring_loaders() && loaders_ok) {     // (not for a launch with the fused BatchNorm-backward reduce, nor for its support query)
             if (id == 15 && nchunks >= 128) id = 24;      // (12 K-steps, 768 -> 128 @80^2: 42.8 against 41.2 us — the staggered form keeps it)
             if (id == 9 && b128 >= 64) id = 25;
+            // the two-CTA 128 x 128 ring where it is NOT walked persistently (fewer than 2.5 tiles per resident CTA): 4 multiplier waves of
+            // 64 x 64 + 4 loader waves, two stages, two CTAs per CU (128 registers) — 3..8 % faster than the 8-wave form (512->512 @40^2
+            // forward 31.4 -> 29.6 us, dgrad 28.6 -> 26.2; 768->128 @80^2 42.3 -> 40.2); the persistent walk keeps the many-tile layers
+            // (64->128 k3s2 @160^2: 112 against 123 us)
+            if (id == 7 && b128 < 1280) id = 29;
         }
         if (Cst < 128) id = ring64;
         if (forced >= 0) id = forced;
