@@ -9,14 +9,14 @@ check=0
 if [ "$1" = "--check" ]; then check=1; shift; fi
 f=${1:-igemm.hip}
 cd "$(dirname "$0")/../yolo_dual_amd/csrc" || exit 1
-tab=$(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -c "$f" -o /tmp/_kr.o \
+tab=$(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-result -I../../include -I. -c "$f" -o /tmp/_kr.o \
     -Rpass-analysis=kernel-resource-usage 2>&1 |
     grep -E "Function Name|VGPRs:|AGPRs|Occupancy|VGPRs Spill" | sed 's/.*remark: //; s/\[-Rpass.*//' | paste - - - - -)
 if [ $check = 0 ]; then echo "$tab"; exit 0; fi
 
 # guarded instantiations (the ones the default bench step launches): mangled-name pattern, least waves/SIMD, most spilled VGPRs.
 # A spill entry above 0 is a spill OUTSIDE the main loop that was looked at in the assembly (igemm2s<..,2,..>: one 8-byte store before
-# the K loop and its reload after it; igemm2p<128,128,8,4,bnred>: one dword in the epilogue).
+# the K loop and its reload after it).  The table is compiled with the flags of yolo_dual_amd/build.py.
 guard='
 igemm2_kernelILi128ELi128ELi8ELi4ELi2ELb0ELi0E 4 0
 igemm2_kernelILi256ELi128ELi8ELi4ELi3ELb0ELi1E 2 0
@@ -28,9 +28,10 @@ igemm2w_kernelILi128ELb0ELi4E 2 0
 igemm2s_kernelILi8ELi4ELi2ELb0E 4 2
 igemm2s_kernelILi8ELi4ELi2ELb1E 4 2
 igemm2p_kernelILi128ELi128ELi8ELi4ELb0E 4 0
-igemm2p_kernelILi128ELi128ELi8ELi4ELb1E 4 1
+igemm2p_kernelILi128ELi128ELi8ELi4ELb1E 4 0
 igemm2l_kernelILi256ELi128ELi8ELi4ELi3ELi4E 3 0
 igemm2l_kernelILi128ELi128ELi8ELi4ELi3ELi4E 3 0
+igemm2l_kernelILi128ELi128ELi4ELi2ELi2ELi4E 4 0
 wgrad3s_kernelILi128ELi32ELi4ELi4E 4 0
 wgrad3s_kernelILi64ELi32ELi4ELi4E 4 0
 pwbw_kernelILi5ELb0E 5 0
