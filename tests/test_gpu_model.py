@@ -299,14 +299,18 @@ def test_pointwise_streaming_kernel_in_c3_block(mode):
         assert l2_err(a, b) < tol, l2_err(a, b)
 
 
+@pytest.mark.parametrize("family", ["YOLOv5Seg", "YOLOv8Seg", "YOLOv9Seg"])
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_commuted_concat_conv_matches_materialised_concat(mode):
-    """conv1x1(cat(a, bilinear_up(b))) evaluated as conv_a(a) + bilinear_up(conv_b(b)) (virtual concat, column-block weight
-    gradients) == the plain path (resize b, concat, one conv) on the whole yolov5 model: prediction, loss, every gradient."""
+def test_commuted_concat_conv_matches_materialised_concat(mode, family):
+    """conv1x1(cat(a, up(b))) evaluated as conv_a(a) + up(conv_b(b)) (virtual concat, column-block weight gradients) == the plain path
+    (up-sample b, concat, one conv) on whole models: prediction, loss, every gradient.  yolov5: ``up`` is the Concat's own bilinear
+    auto-align (seg_diceloss_yolov5.py:484-507); yolov8 / yolov9: an nn.Upsample(nearest) in front of the Concat
+    (yolov8/seg_jaccardloss_yolov8.py head rows), which reaches the Concat as a lazily replicated tensor (round 5)."""
     import yolo_dual_amd as ydl
     from yolo_dual_amd import config
     ydl.set_compute_dtype(mode)
-    cfg = _cfg("yolov5_seg.yaml", {"C3_DCN": "C3"})
+    cfg = {"YOLOv5Seg": _cfg("yolov5_seg.yaml", {"C3_DCN": "C3"}), "YOLOv8Seg": _cfg("yolov8_seg.yaml", {"C2f_DCN": "C2f"}),
+           "YOLOv9Seg": _cfg("yolov9_seg.yaml", {})}[family]
     res = []
     # the deterministic forms on both sides, so that the backbone (identical in the two arms) contributes nothing and the difference
     # is the head algebra alone: throughput mode's atomically added BN sums differ in their last bits from run to run, which at
@@ -316,7 +320,7 @@ def test_commuted_concat_conv_matches_materialised_concat(mode):
     for on in (True, False):
         config.set_commute_concat(on)
         try:
-            m = ydl.YOLOv5Seg(cfg)
+            m = getattr(ydl, family)(cfg)
             m.img_size = [128, 128]
             sd = m.state_dict()
             fill_state_dict(sd, 5)
