@@ -303,9 +303,9 @@ def test_pointwise_streaming_kernel_in_c3_block(mode):
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_commuted_concat_conv_matches_materialised_concat(mode, family):
     """conv1x1(cat(a, up(b))) evaluated as conv_a(a) + up(conv_b(b)) (virtual concat, column-block weight gradients) == the plain path
-    (up-sample b, concat, one conv) on whole models: prediction, loss, every gradient.  yolov5: ``up`` is the Concat's own bilinear
-    auto-align (seg_diceloss_yolov5.py:484-507); yolov8 / yolov9: an nn.Upsample(nearest) in front of the Concat
-    (yolov8/seg_jaccardloss_yolov8.py head rows), which reaches the Concat as a lazily replicated tensor (round 5)."""
+    (up-sample b, concat, one conv) on whole models: prediction, loss, every gradient.  ``up`` is the Concat's own bilinear
+    auto-align (seg_diceloss_yolov5.py:484-507); the yolov8 / yolov9 heads (explicit nn.Upsample rows, Concat with an earlier
+    backbone layer) go through the same switch and must not change either."""
     import yolo_dual_amd as ydl
     from yolo_dual_amd import config
     ydl.set_compute_dtype(mode)
